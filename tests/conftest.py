@@ -1,0 +1,35 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "mav-detection_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return np.load(os.path.join(GOLDEN, "foe_chain.npz"), allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
+def fb_oracle():
+    """The compiled C restatement of Farneback (oracle/farneback_oracle.c), built on demand."""
+    from oracle import fb_oracle as mod
+    return mod.load()
+
+
+@pytest.fixture(scope="session")
+def mav():
+    """The product library through its ctypes loader; fails loudly when libmavflow.so is missing."""
+    import mavflow
+    return mavflow

@@ -1,0 +1,112 @@
+"""The C restatement of Farneback (oracle/farneback_oracle.c) against analytic ground truth.  CPU only.
+
+PARITY UNPINNED vs cv2 (OpenCV is not in the image, the reference holds no Farneback fixture); these tests
+bound the restatement by known flow instead."""
+import numpy as np
+import pytest
+
+from oracle import fb_oracle
+from mavflow import synth
+
+
+def test_layers_and_dims(fb_oracle):
+    p = fb_oracle_params()
+    assert fb_oracle.num_layers(1920, 1080, p) == 2
+    assert fb_oracle.layer_dims(1920, 1080, p, 1) == (768, 432, 0.75, 5)
+    assert fb_oracle.layer_dims(1920, 1080, p, 0) == (1920, 1080, 0.0, 3)
+    p5 = fb_oracle_params(levels=5)
+    assert fb_oracle.num_layers(3840, 2160, p5) == 5
+    dims = [fb_oracle.layer_dims(3840, 2160, p5, k) for k in range(5)]
+    assert [d[3] for d in dims] == [3, 5, 13, 37, 95]
+    assert dims[4][:2] == (98, 55)
+    assert fb_oracle.num_layers(64, 48, p) == 1            # 0.4 * 48 < 32 -> no coarse layer
+
+
+def fb_oracle_params(levels=1):
+    return fb_oracle_mod().default_params(levels)
+
+
+def fb_oracle_mod():
+    from oracle import fb_oracle as m
+    return m
+
+
+def test_polyexp_on_quadratic(fb_oracle):
+    """A quadratic image is reproduced exactly by the polynomial expansion away from the border."""
+    h, w = 64, 80
+    y, x = np.mgrid[0:h, 0:w].astype(np.float64)
+    cx, cy = 40.0, 30.0
+    a, b, c, d, e = 0.7, -0.3, 0.02, 0.015, -0.01      # x, y, xx, yy, xy
+    I = 100 + a * (x - cx) + b * (y - cy) + c * (x - cx) ** 2 + d * (y - cy) ** 2 + e * (x - cx) * (y - cy)
+    R = fb_oracle.polyexp(I.astype(np.float32))
+    s = np.s_[10:-10, 10:-10]
+    gx = a + 2 * c * (x - cx) + e * (y - cy)
+    gy = b + 2 * d * (y - cy) + e * (x - cx)
+    np.testing.assert_allclose(R[..., 1][s], gx[s], atol=2e-3)      # x-linear
+    np.testing.assert_allclose(R[..., 0][s], gy[s], atol=2e-3)      # y-linear
+    np.testing.assert_allclose(R[..., 3][s], c, atol=2e-4)          # xx
+    np.testing.assert_allclose(R[..., 2][s], d, atol=2e-4)          # yy
+    np.testing.assert_allclose(R[..., 4][s], e, atol=2e-4)          # xy
+
+
+def test_blur_resize_identity_and_constant(fb_oracle):
+    img = np.full((48, 64), 77, np.uint8)
+    out = fb_oracle.blur_resize(img, 64, 48, 3, 0.0)
+    np.testing.assert_allclose(out, 77.0, atol=1e-4)
+    out = fb_oracle.blur_resize(img, 26, 19, 5, 0.75)
+    np.testing.assert_allclose(out, 77.0, atol=1e-4)
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (48, 64)).astype(np.uint8)
+    out = fb_oracle.blur_resize(img, 64, 48, 3, 0.0)
+    f = img.astype(np.float64)
+    p = np.pad(f, 1, mode="reflect")
+    k = np.array([0.25, 0.5, 0.25])
+    ref = sum(k[i] * k[j] * p[i:i + 48, j:j + 64] for i in range(3) for j in range(3))
+    np.testing.assert_allclose(out, ref, atol=1e-3)
+
+
+@pytest.mark.parametrize("shift", [(1.5, -0.75), (-3.0, 2.0)])
+def test_uniform_translation(fb_oracle, shift):
+    """Pure translation of a smooth texture: interior flow equals the shift."""
+    W, H = 320, 240
+    rng = np.random.default_rng(5)
+    fx, fy, amp, ph = synth._texture_params(rng)
+    x = np.arange(W, dtype=np.float64); y = np.arange(H, dtype=np.float64)
+    t0 = synth._eval_separable(x, y, fx, fy, amp, ph)
+    t1 = synth._eval_separable(x - shift[0], y - shift[1], fx, fy, amp, ph)
+    A = 119.5 / np.abs(t0).max()
+    f0 = np.rint(127.5 + A * t0).astype(np.uint8)
+    f1 = np.clip(np.rint(127.5 + A * t1), 0, 255).astype(np.uint8)
+    flow = fb_oracle.calc(f0, f1)
+    s = np.s_[30:-30, 30:-30]
+    err = np.hypot(flow[..., 0][s] - shift[0], flow[..., 1][s] - shift[1])
+    assert err.mean() < 0.05, err.mean()
+    assert np.percentile(err, 99) < 0.3
+
+
+def test_radial_flow_640x480(fb_oracle):
+    """BASELINE config 1 plumbing: 640x480 synthetic pair, flow close to the analytic field away from the patch."""
+    W, H = 640, 480
+    f0, f1, truth = synth.make_pair(W, H, 0)
+    flow = fb_oracle.calc(f0, f1)
+    err = np.hypot(flow[..., 0] - truth[..., 0], flow[..., 1] - truth[..., 1])
+    inner = np.ones((H, W), bool)
+    inner[:20] = inner[-20:] = False
+    inner[:, :20] = inner[:, -20:] = False
+    inner[H // 4 - 24:H // 4 + 48, W // 4 - 24:W // 4 + 48] = False
+    assert err[inner].mean() < 0.1, err[inner].mean()
+    # the 24x24 moving patch is smaller than the 13x13 window at the coarse layer, so Farneback only registers
+    # it as a disturbance of the radial field -- which is all the detector needs
+    radial = synth.true_flow(W, H, patch=False)
+    dev = np.hypot(flow[..., 0] - radial[..., 0], flow[..., 1] - radial[..., 1])
+    assert dev[H // 4:H // 4 + 24, W // 4:W // 4 + 24].mean() > 5 * err[inner].mean()
+
+
+def test_bad_arguments(fb_oracle):
+    a = np.zeros((48, 64), np.uint8)
+    with pytest.raises(ValueError):
+        fb_oracle.calc(a, np.zeros((48, 65), np.uint8))
+    p = fb_oracle_params()
+    p.pyr_scale = 1.0
+    with pytest.raises(ValueError):
+        fb_oracle.calc(a, a, p)

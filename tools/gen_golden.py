@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own Python on seeded inputs.
+
+Run in the build container only (needs /root/reference):   python tools/gen_golden.py
+The reference is imported in place; nothing of it is copied.  cv2 / imutils / flow_vis / airsim are not
+installed here, and none of the functions exercised below touches them, so empty placeholder modules stand
+in for the import statements (SURVEY.md section 8c recipe).  Bytecode writing is disabled so the read-only
+reference tree is left untouched.
+"""
+import sys
+
+sys.dont_write_bytecode = True
+import os
+import types
+
+import numpy as np
+
+REF = "/root/reference/src"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, os.path.join(ROOT, "mav-detection_amd"))
+
+
+def _placeholders():
+    import matplotlib
+    matplotlib.use("Agg")
+    cv2 = types.ModuleType("cv2")
+    cv2.TERM_CRITERIA_EPS = 2
+    cv2.TERM_CRITERIA_COUNT = 1
+    cv2.COLORMAP_JET = 2
+    cv2.VideoCapture = object
+    cv2.VideoWriter = object
+    for name, mod in (("cv2", cv2), ("imutils", types.ModuleType("imutils")),
+                      ("flow_vis", types.ModuleType("flow_vis")), ("airsim", types.ModuleType("airsim"))):
+        sys.modules.setdefault(name, mod)
+    sys.path.insert(0, REF)
+
+
+class _FakeDataset:
+    """Duck-typed stand-in for datasets.dataset.Dataset: only what Detector.__init__/derotate read."""
+
+    def __init__(self, W, H, dangle, dt):
+        self.capture_size = (W, H)
+        self._dangle = np.asarray(dangle, dtype=np.float64)
+        self._dt = dt
+
+    def get_delta_time(self, i):
+        return self._dt
+
+    def get_angular_difference(self, a, b):
+        return self._dangle
+
+
+def main():
+    _placeholders()
+    import focus_of_expansion as ref_foe
+    import im_helpers as ref_im
+    import lucas_kanade as ref_lk
+    import utils as ref_utils
+    from mavflow import synth
+
+    os.makedirs(OUT, exist_ok=True)
+    out = {}
+
+    # ---- line_intersection (utils.py:183-197) ---------------------------------------------------------
+    rng = np.random.default_rng(1)
+    L = 64
+    pts = rng.integers(0, 500, (L, 2, 2)).astype(np.uint32)          # (x, y) of the two base points
+    fl = rng.normal(0, 4, (L, 2, 2)).astype(np.float32)
+    fl[5, 1] = fl[5, 0]                                               # parallel pair -> (False, False)
+    fl[9] = 0                                                         # degenerate: both lines are points
+    res = np.zeros((L, 2))
+    for i in range(L):
+        c1, c2 = pts[i, 0], pts[i, 1]
+        res[i, :] = ref_utils.line_intersection((c1, fl[i, 0] + c1), (c2, fl[i, 1] + c2))
+    out.update(li_pts=pts, li_flow=fl, li_out=res)
+
+    # ---- FoE dense + ransac + phi on small stored fields ----------------------------------------------
+    W, H = 160, 120
+    lk = ref_lk.LucasKanade(np.zeros((H, W, 3), np.uint8))
+    foe = ref_foe.FocusOfExpansion(lk)
+
+    def ref_get_foe(flow, seed):
+        np.random.seed(seed)
+        return foe.get_FOE_dense(flow)
+
+    def samples_for(seed, h, w, n=1000):
+        np.random.seed(seed)
+        s = np.zeros((2 * n, 2), np.uint32)
+        s[:, 0] = np.random.randint(0, h, 2 * n)
+        s[:, 1] = np.random.randint(0, w, 2 * n)
+        return s
+
+    flows, foes, seeds, phis = [], [], [], []
+    for case in range(4):
+        f = synth.true_flow(W, H, k=0.08, patch=True)
+        f += np.random.default_rng(50 + case).normal(0, 0.3, f.shape)
+        f = f.astype(np.float32 if case % 2 == 0 else np.float64)
+        if case == 3:
+            f[:, : W // 2] = 0                                        # half the field below the magnitude gate
+        seed = 99 + case
+        e = ref_get_foe(f, seed)
+        flows.append(f.astype(np.float64))                            # exact (f32 -> f64)
+        foes.append(e)
+        seeds.append(seed)
+        phis.append(foe.get_phi(f.astype(np.float64), e))
+    out.update(foe_flow=np.stack(flows), foe_flow_is_f32=np.array([1, 0, 1, 0]), foe_seed=np.array(seeds),
+               foe_out=np.array(foes), phi_out=np.stack(phis))
+    for case in range(4):
+        out[f"foe_samples_{case}"] = samples_for(seeds[case], H, W)
+
+    # all-zero flow -> (0, 0)
+    out["foe_zero"] = np.array(ref_get_foe(np.zeros((H, W, 2), np.float32), 5))
+
+    # ransac edge cases (focus_of_expansion.py:32-54)
+    iso = np.array([[0.0, 0.0], [100.0, 0.0], [0.0, 100.0], [300.0, 300.0]])
+    tie = np.array([[10.0, 10.0], [12.0, 10.0], [500.0, 500.0], [501.0, 500.0]])
+    clus = np.concatenate([rng.normal(50, 5, (40, 2)), rng.normal(300, 40, (60, 2))])
+    out.update(ransac_iso_in=iso, ransac_iso_out=np.array(foe.ransac(iso)),
+               ransac_tie_in=tie, ransac_tie_out=np.array(foe.ransac(tie)),
+               ransac_clus_in=clus, ransac_clus_out=np.array(foe.ransac(clus)),
+               ransac_empty_out=np.array(foe.ransac(np.zeros((0, 2)))))
+
+    # phi special cases (focus_of_expansion.py:150-184)
+    fz = flows[1].copy()
+    fz[10:20, 10:20] = 0.0                                            # zero-flow pixels -> 90 deg
+    out.update(phi_zero_flow_in=fz, phi_zero_flow_out=foe.get_phi(fz, (70.5, 40.25)),
+               phi_nan_identity_len=np.array(foe.get_phi(fz, (np.nan, np.nan)).shape[0]),
+               phi_float_nan_out=foe.get_phi(fz, (float("nan"), 3.0)))
+    # FoE exactly on a pixel centre: distance 0 -> norm floor 1e-6
+    out.update(phi_on_pixel_out=foe.get_phi(flows[1], (80.0, 60.0)))
+    # float32 flow keeps float32 arithmetic in the reference (zeros_like): record dtype + values
+    p32 = foe.get_phi(flows[0].astype(np.float32), foes[0])
+    out.update(phi_f32_out=p32, phi_f32_dtype=np.array(str(p32.dtype)))
+
+    # ---- threshold block (processor.py:333-341), literally ---------------------------------------------
+    phi = phis[1]
+    flow_mag = ref_im.get_magnitude(flows[1])
+    sky_mask = np.zeros((H, W), dtype=bool)
+    sky_mask[:15, :] = True
+    for tag, sky in (("nosky", np.zeros((H, W), dtype=bool)), ("sky", sky_mask)):
+        with np.errstate(all="ignore"):
+            angle_threshold_max = phi > (0.25 + (0.5 + 8 / flow_mag))
+            angle_threshold_min = phi < (0.25 - (0.5 + 8 / flow_mag))
+            angle_threshold = np.logical_or(angle_threshold_min, angle_threshold_max)
+            total_mask = (flow_mag > 0.5) * ~sky * angle_threshold
+            fixed_angle_threshold = 15
+            estimate_fixed = phi * (flow_mag > 1.0) * ~sky > fixed_angle_threshold
+        out[f"thr_{tag}_total"] = total_mask
+        out[f"thr_{tag}_fixed"] = estimate_fixed
+    out["thr_sky"] = sky_mask
+    out["mag_out"] = flow_mag
+
+    # ---- get_simple_bounding_box (im_helpers.py:55-84) -------------------------------------------------
+    m = np.zeros((H, W), np.uint8)
+    m[5:9, 7:20] = 255
+    r = ref_im.get_simple_bounding_box(m)
+    out.update(bbox_a_in=m, bbox_a=np.array([r.topleft[0], r.topleft[1], r.size[0], r.size[1]]))
+    r = ref_im.get_simple_bounding_box(np.zeros((H, W), np.uint8))
+    out.update(bbox_empty=np.array([r.topleft[0], r.topleft[1], r.size[0], r.size[1]]))
+    g = (rng.integers(0, 256, (H, W)) * (rng.random((H, W)) > 0.995)).astype(np.uint8)
+    g[:, :3] = 0
+    g[40, 100] = 250
+    r = ref_im.get_simple_bounding_box(g)
+    out.update(bbox_gray_in=g, bbox_gray=np.array([r.topleft[0], r.topleft[1], r.size[0], r.size[1]]))
+    r = ref_im.get_simple_bounding_box(out["thr_nosky_fixed"])
+    out.update(bbox_fixed=np.array([r.topleft[0], r.topleft[1], r.size[0], r.size[1]]))
+
+    # ---- calculate_tpr_fpr (im_helpers.py:244-252) -----------------------------------------------------
+    gt = np.zeros((H, W), np.uint8)
+    gt[30:60, 40:70] = 255
+    with np.errstate(all="ignore"):
+        t = ref_im.calculate_tpr_fpr(gt, 255 * out["thr_nosky_fixed"])
+    out.update(tpr_gt=gt, tpr_out=np.array(t, dtype=np.float64))
+
+    # ---- Rectangle (utils.py:13-104) -------------------------------------------------------------------
+    r1 = ref_utils.Rectangle.from_points((7, 5), (19, 8))
+    r2 = ref_utils.Rectangle.from_center((15.0, 8.0), (10.0, 6.0))
+    out.update(rect_vals=np.array([*r1.topleft, *r1.size, *r1.get_center(), r1.get_area(),
+                                   ref_utils.Rectangle.calculate_iou(r1, r2),
+                                   ref_utils.Rectangle((0, 0), (0, 0)).get_area()], dtype=np.float64),
+               rect_yolo=np.array(r1.to_yolo(np.array([W, H]))))
+
+    # ---- derotate (detector.py:70-117) -----------------------------------------------------------------
+    import detector as ref_det
+    dangle = np.array([0.013, -0.021, 0.008])
+    dt = 1.0 / 30.0
+    det = ref_det.Detector(_FakeDataset(W, H, dangle, dt))
+    f32 = flows[0].astype(np.float32)
+    out.update(derot_in=f32, derot_dangle=dangle, derot_dt=np.array(dt),
+               derot_out=det.derotate(0, 1, f32), derot_frame0_same=np.array(det.derotate(-1, 0, f32) is f32))
+    # enum surface (names + values)
+    out["algo_names"] = np.array([a.name for a in ref_det.Detector.Algorithm])
+    out["algo_values"] = np.array([a.value[0] for a in ref_det.Detector.Algorithm])
+
+    # ---- full chain at 640x480 from the seeded recipe (inputs are regenerated, not stored) ------------
+    W2, H2 = 640, 480
+    lk2 = ref_lk.LucasKanade(np.zeros((H2, W2, 3), np.uint8))
+    foe2 = ref_foe.FocusOfExpansion(lk2)
+    fl2 = synth.synthetic_flow(W2, H2, seed=3)                         # float32
+    det2 = ref_det.Detector(_FakeDataset(W2, H2, dangle, dt))
+    der2 = det2.derotate(0, 1, fl2)
+    smp = synth.foe_samples(W2, H2, 0)
+    np.random.seed(1234)
+    e2 = foe2.get_FOE_dense(der2)
+    phi2 = foe2.get_phi(der2, e2)
+    mag2 = ref_im.get_magnitude(der2)
+    nosky = np.zeros((H2, W2), dtype=bool)
+    with np.errstate(all="ignore"):
+        hi = phi2 > (0.25 + (0.5 + 8 / mag2))
+        lo = phi2 < (0.25 - (0.5 + 8 / mag2))
+        total2 = (mag2 > 0.5) * ~nosky * np.logical_or(lo, hi)
+        fixed2 = phi2 * (mag2 > 1.0) * ~nosky > 15
+    r = ref_im.get_simple_bounding_box(fixed2)
+    out.update(chain_foe=np.array(e2), chain_samples_sum=np.array(int(smp.astype(np.int64).sum())),
+               chain_fixed_bits=np.packbits(fixed2), chain_total_bits=np.packbits(total2),
+               chain_phi_sub=phi2[::16, ::16].copy(), chain_box=np.array([r.topleft[0], r.topleft[1], r.size[0], r.size[1]]),
+               chain_max_flow=np.array(foe2.max_flow))
+
+    np.savez_compressed(os.path.join(OUT, "foe_chain.npz"), **out)
+    print("wrote", os.path.join(OUT, "foe_chain.npz"), {k: getattr(v, "shape", None) for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    main()
