@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py -- frame-pairs/s of the hot path (frames -> Farneback flow -> FoE -> phi -> masks -> box) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N = 1: this process; N > 1: launched by torch.distributed.run)
+
+A step is one pass of the whole path over one batch of synthetic 1920x1080 pairs (BASELINE config 3: batch 64 per
+GPU) with the frames already resident in HBM.  Prints ONE JSON line (rank 0).  Multi-GPU: every rank runs its own
+batch (weak scaling, no data-path collective) and the per-pair 32-byte result records are all-gathered over
+RCCL/xGMI at the end of each step, inside the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "mav-detection_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+ITER_BYTES_UPDATE = 88           # per pixel per sweep: read M 20 + R0 20 + R1 20, write M' 20 + flow 8   
+ITER_BYTES_LAST = 28             # last sweep of a layer: read M 20, write flow 8
+
+
+def b_alg_per_pair(layers, W, H, iters):
+    """Algorithmic bytes of one pair, SURVEY 8(d): per layer blur+resize 2(P0+4n), polyexp 2(4n+20n), initial M 60n
+    (+8 n_coarser), sweeps (I-1)*88n + 28n; then phi+threshold 9 P0 and box 1 P0."""
+    P0 = W * H
+    tot = 0
+    for k, (w, h) in enumerate(layers):
+        n = w * h
+        tot += 2 * (P0 + 4 * n) + 2 * (4 * n + 20 * n) + 60 * n + (iters - 1) * ITER_BYTES_UPDATE * n + ITER_BYTES_LAST * n
+        if k + 1 < len(layers):
+            tot += 8 * layers[k + 1][0] * layers[k + 1][1]
+    return tot + 10 * P0
+
+
+def cpu_baseline(prev, nxt, samples, n_sample):
+    """The oracle (C restatement of Farneback + numpy FoE chain) on a bounded sample of the same workload, 1 core."""
+    import numpy as np
+    from oracle import fb_oracle, foe_oracle
+    orc = fb_oracle.load()
+    t0 = time.perf_counter()
+    for b in range(n_sample):
+        flow = orc.calc(prev[b], nxt[b])
+        foe_oracle.run_chain(flow, samples[b])
+    dt = time.perf_counter() - t0
+    return {"value": n_sample / dt, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
+            "sample": f"{n_sample} of the benchmark's 1920x1080 pairs, oracle/farneback_oracle.c (restatement, not OpenCV: "
+                      f"cv2 is absent) + numpy FoE chain, {dt:.1f} s, host has {os.cpu_count()} cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="pairs per GPU per step")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--group", type=int, default=0, help="pairs per launch (0 = library default)")
+    ap.add_argument("--cpu-pairs", type=int, default=3, help="pairs in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    torch = None
+    if world > 1 or os.environ.get("MAVFLOW_BENCH_DIST") == "1":
+        # torch first: libmavflow then binds to the HIP runtime torch already loaded (same SONAME), one runtime per process
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import numpy as np
+    from mavflow import _lib, synth
+
+    W, H, B = args.width, args.height, args.batch
+    ctx = _lib.Context(W, H, B, device=local_rank)
+    if args.group:
+        ctx.set_option("group", args.group)
+    layers = [ctx.layer_dims(k)[:2] for k in range(ctx.num_layers())]
+
+    prev, nxt = synth.make_batch(W, H, B, distinct=4)
+    if rank:                                           # different content per rank
+        prev = np.roll(prev, 31 * rank, axis=2); nxt = np.roll(nxt, 31 * rank, axis=2)
+    samples = np.stack([synth.foe_samples(W, H, rank * B + b) for b in range(B)])
+    d_prev = ctx.alloc(prev.nbytes).upload(prev)
+    d_next = ctx.alloc(nxt.nbytes).upload(nxt)
+    d_smp = ctx.alloc(samples.nbytes).upload(samples)
+    rec = _lib.RESULT_DTYPE.itemsize
+    if dist is not None:
+        t_local = torch.empty(B * rec, dtype=torch.uint8, device="cuda")
+        t_all = torch.empty(world * B * rec, dtype=torch.uint8, device="cuda")
+        res_ptr = t_local.data_ptr()
+    else:
+        d_res = ctx.alloc(B * rec)
+        res_ptr = d_res.ptr
+
+    def step():
+        # flow stays in the library's HBM workspace (flow_ptr=None); masks are not requested: the box is the output
+        ctx.process_batch_dev(d_prev.ptr, d_next.ptr, d_smp.ptr, B, res_ptr)
+        if dist is not None:
+            ctx.sync()
+            dist.all_gather_into_tensor(t_all, t_local)
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    for _ in range(args.steps):
+        step()
+    ev_ms = ctx.timer_stop()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline of the dominant kernel (separate pass, HIP events around every launch on the context's stream) ----
+    roofline = None
+    if rank == 0 and not args.no_profile:
+        ctx.profile_enable(True)
+        ctx.process_batch_dev(d_prev.ptr, d_next.ptr, d_smp.ptr, B, res_ptr)
+        prof = ctx.profile_get()
+        ctx.profile_enable(False)
+        ms, launches = prof["blur_iter"]
+        iters = ctx.fb.iterations
+        bytes_step = B * sum(w * h * ((iters - 1) * ITER_BYTES_UPDATE + ITER_BYTES_LAST) for (w, h) in layers)
+        achieved = bytes_step / (ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "k_blur_iter", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "avg_launch_ms": round(ms / max(launches, 1), 4), "launches_per_step": launches,
+                    "alg_bytes_per_launch_avg": int(bytes_step / max(launches, 1)),
+                    "kernel_share_of_step": round(ms / (1e3 * elapsed / args.steps), 3),
+                    "all_kernels_ms": {k: round(v[0], 3) for k, v in prof.items()}}
+
+    if rank == 0:
+        pairs = world * B * args.steps
+        value = pairs / elapsed
+        balg = b_alg_per_pair(layers, W, H, ctx.fb.iterations)
+        out = {"metric": "frame-pairs/sec at 1920x1080" if (W, H) == (1920, 1080) else f"frame-pairs/sec at {W}x{H}",
+               "value": round(value, 2), "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"{W}x{H}, batch={B} frame pairs per GPU, Farneback(0.4,{ctx.fb.levels},12,10,8,1.2,0) "
+                                      f"+ FoE(1000 pairs) + phi/threshold + box, {len(layers)} pyramid layers",
+                          "global_batch": world * B, "parallelism": f"frame-parallel x{world}" + (", RCCL all-gather of 32-B records" if world > 1 else "")},
+               "hip_event_ms_per_step": round(ev_ms / args.steps, 3),
+               "pipeline_alg_bytes_per_pair": balg,
+               "pipeline_frac_of_hbm_peak": round(value / world * balg / (HBM_PEAK_GBS * 1e9), 4)}
+        if roofline:
+            out["roofline"] = roofline
+        if world == 1 and args.cpu_pairs > 0:
+            out["cpu_baseline"] = cpu_baseline(prev, nxt, samples, min(args.cpu_pairs, B))
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,152 @@
+/*
+ * mavflow.h -- C-ABI of libmavflow.so: the MI355X (gfx950) replacement for the per-frame-pair vision math of
+ * evroon/mav-detection (Farneback flow -> derotation -> FoE fit -> phi -> threshold masks -> box).
+ *
+ * The reference is pure Python with no FFI of its own; each entry point below replaces the Python call cited
+ * next to it (paths relative to the reference root) and is bound through ctypes (INTEGRATION.md shows the stub
+ * a maintainer adds on the reference side).
+ *
+ * Conventions
+ *   - plain C, no torch types; every buffer is caller-allocated, C-contiguous, never retained past the call.
+ *   - entry points without a suffix take HOST pointers and are synchronous; `_dev` variants take DEVICE
+ *     pointers (hipMalloc'd by anyone in this process, e.g. mav_dev_alloc or a torch tensor's data_ptr()),
+ *     enqueue on the context's stream and return without synchronising (call mav_sync).
+ *   - return value: 0 = OK, <0 = error (MAV_ERR_*); mav_last_error() gives the message. No abort(), no C++
+ *     exceptions cross the boundary.
+ *   - a mav_ctx is single-threaded (as the reference's loop is); distinct contexts are independent.
+ *   - images are (batch, H, W) u8; flow is (batch, H, W, 2) interleaved (u, v); masks are (batch, H, W) u8 0/1.
+ */
+#ifndef MAVFLOW_H
+#define MAVFLOW_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MAV_OK 0
+#define MAV_ERR_ARG (-1)   /* bad argument (NULL, size mismatch, pyr_scale >= 1 ...): cv2.error / ValueError in the shim */
+#define MAV_ERR_HIP (-2)   /* a HIP runtime call failed */
+#define MAV_ERR_OOM (-3)   /* device allocation failed */
+#define MAV_ERR_STATE (-4) /* context unusable / no GPU */
+
+typedef struct mav_ctx mav_ctx;
+
+/* src/farneback.py:76-80 -- the literal argument list of cv2.calcOpticalFlowFarneback.
+ * Defaults (mav_fb_defaults): 0.4, 1, 12, 10, 8, 1.2, 0. Only flags == 0 (box window) is implemented. */
+typedef struct {
+    double pyr_scale;
+    int levels, winsize, iterations, poly_n;
+    double poly_sigma;
+    int flags;
+} mav_fb_params;
+
+/* src/focus_of_expansion.py:21-23,67 -- N = 1000 line pairs, |flow2| gate 2.5, RANSAC radius 30 px. */
+typedef struct {
+    int n_pairs;
+    double mag_threshold, ransac_threshold;
+} mav_foe_params;
+
+/* src/processor.py:333-341 -- fixed: phi*(mag > fixed_min_mag)*~sky > fixed_deg;
+ * dynamic: (mag > dyn_min_mag) * ~sky * (phi > dyn_a + (dyn_b + dyn_c/mag) | phi < dyn_a - (dyn_b + dyn_c/mag)).
+ * Defaults: 15, 1.0, 0.5, 0.25, 0.5, 8. */
+typedef struct {
+    double fixed_deg, fixed_min_mag, dyn_min_mag, dyn_a, dyn_b, dyn_c;
+} mav_thr_params;
+
+/* One record per frame pair: what the multi-GPU all-gather moves (32 bytes). box = x0, y0, x1, y1 inclusive
+ * of the fixed-threshold mask (src/im_helpers.py:55-84 semantics), all -1 when the mask is empty. */
+typedef struct {
+    int32_t box[4];
+    double foe[2];
+} mav_result;
+
+void mav_fb_defaults(mav_fb_params*);
+void mav_foe_defaults(mav_foe_params*);
+void mav_thr_defaults(mav_thr_params*);
+
+/* ---- context ------------------------------------------------------------------------------------------- */
+/* One context per (device, W, H, max_batch); owns its stream, pyramid tables and workspace. */
+int mav_create(mav_ctx** out, int device, int W, int H, int max_batch, const mav_fb_params* fb /* NULL = defaults */);
+int mav_destroy(mav_ctx*);
+const char* mav_last_error(void); /* thread-local, never NULL */
+int mav_device_count(void);       /* <= 0 when no GPU is visible */
+/* Tuning: name = "group" (pairs processed per launch, >= 1). Returns MAV_ERR_ARG for unknown names. */
+int mav_set_option(mav_ctx*, const char* name, long value);
+int mav_num_layers(const mav_ctx*);
+int mav_layer_dims(const mav_ctx*, int k, int* w, int* h, int* ksize, double* sigma);
+
+/* ---- host-pointer entry points (synchronous) ----------------------------------------------------------- */
+/* cv2.calcOpticalFlowFarneback(prev, next, None, *fb)   [src/farneback.py:76-80] for `batch` pairs. */
+int mav_farneback(mav_ctx*, const uint8_t* prev, const uint8_t* next, int batch, float* flow);
+/* Detector.derotate [src/detector.py:70-117]: omega = angular difference / dt, (batch,3); dt (batch). */
+int mav_derotate(mav_ctx*, const float* flow, const double* omega, const double* dt, int batch, double* flow_out);
+/* FocusOfExpansion.get_FOE_dense + ransac [src/focus_of_expansion.py:32-86]; samples (batch, 2N, 2) = (row, col)
+ * drawn by the caller exactly as :70-71 does (the GPU never generates them). foe (batch, 2). */
+int mav_foe_dense(mav_ctx*, const double* flow, const uint32_t* samples, int batch, const mav_foe_params*, double* foe);
+/* FocusOfExpansion.get_phi [src/focus_of_expansion.py:150-184] + threshold block [src/processor.py:333-341].
+ * sky: (batch,H,W) u8 or NULL; phi (degrees), mask_fixed, mask_dyn, max_phi (batch) are each optional (NULL). */
+int mav_phi_mask(mav_ctx*, const double* flow, const double* foe, const uint8_t* sky, int batch, const mav_thr_params*,
+                 double* phi, uint8_t* mask_fixed, uint8_t* mask_dyn, double* max_phi);
+/* im_helpers.get_simple_bounding_box [src/im_helpers.py:55-84] on u8 images: box (batch,4) = x0,y0,x1,y1, -1 if empty. */
+int mav_bbox(mav_ctx*, const uint8_t* img, int batch, int32_t* box);
+/* Level 0 of Detector.analyze_pyramid [src/detector.py:280-312] on the 3-channel replica of a u8 image:
+ * out (batch,3) = score, x, y of the first 64x64 / stride-16 window with the strictly largest sum. */
+int mav_window_max(mav_ctx*, const uint8_t* img, int batch, int64_t* out);
+/* im_helpers.calculate_tpr_fpr [src/im_helpers.py:244-252] for a 0/255 ground truth and a 0/1 mask:
+ * counts (batch,4) = positives, negatives, true positives, false positives. */
+int mav_tpr_fpr_counts(mav_ctx*, const uint8_t* gt, const uint8_t* mask, int batch, int64_t* counts);
+
+/* The fused loop body of Processor.run_detection [src/processor.py:305-341] for `batch` pairs:
+ * frames -> flow -> (derotate) -> FoE -> phi -> masks -> box. omega/dt NULL = no rotation (dt = 1);
+ * sky NULL = no sky; flow / mask_fixed / mask_dyn / phi outputs are optional (NULL). results (batch). */
+int mav_process_batch(mav_ctx*, const uint8_t* prev, const uint8_t* next, const uint32_t* samples, const double* omega,
+                      const double* dt, const uint8_t* sky, int batch, const mav_foe_params*, const mav_thr_params*,
+                      float* flow, double* phi, uint8_t* mask_fixed, uint8_t* mask_dyn, mav_result* results);
+
+/* ---- device-pointer entry points (asynchronous on the context's stream) -------------------------------- */
+int mav_farneback_dev(mav_ctx*, const uint8_t* prev, const uint8_t* next, int batch, float* flow);
+int mav_process_batch_dev(mav_ctx*, const uint8_t* prev, const uint8_t* next, const uint32_t* samples, const double* omega,
+                          const double* dt, const uint8_t* sky, int batch, const mav_foe_params*, const mav_thr_params*,
+                          float* flow, double* phi, uint8_t* mask_fixed, uint8_t* mask_dyn, mav_result* results);
+int mav_sync(mav_ctx*);
+void* mav_stream(mav_ctx*); /* the context's hipStream_t */
+
+/* device memory + copies for callers without their own HIP binding */
+int mav_dev_alloc(mav_ctx*, size_t bytes, void** out);
+int mav_dev_free(mav_ctx*, void* p);
+int mav_memcpy_h2d(mav_ctx*, void* dst, const void* src, size_t bytes);
+int mav_memcpy_d2h(mav_ctx*, void* dst, const void* src, size_t bytes);
+
+/* HIP-event timing on the context's stream (bench.py): start/stop bracket enqueued work; stop synchronises. */
+int mav_timer_start(mav_ctx*);
+int mav_timer_stop(mav_ctx*, float* ms);
+/* Per-kernel-class profiling with HIP events around every launch (separate pass, never inside a timed region).
+ * mav_profile_get: name[i] / total_ms[i] / launches[i] for i < *n (caller passes capacity in *n). */
+int mav_profile_enable(mav_ctx*, int on);
+int mav_profile_get(mav_ctx*, int* n, const char** names, double* total_ms, long* launches);
+
+/* multi-GPU: gather `bytes_per_rank` bytes from every rank (RCCL ncclAllGather over xGMI) on the context's stream.
+ * comm is an ncclComm_t created by the caller (mav_comm_* helpers below wrap RCCL's own bootstrap). */
+int mav_comm_unique_id(void* id128 /* 128 bytes out */);
+int mav_comm_init(mav_ctx*, const void* id128, int rank, int nranks, void** comm_out);
+int mav_comm_destroy(void* comm);
+int mav_allgather_results(mav_ctx*, void* comm, const void* local_dev, size_t bytes_per_rank, void* all_dev);
+
+/* ---- stage hooks (diagnostics / parity tests; host pointers, one image or pair, SoA planes) ------------- */
+/* layer image I_k of one frame: convertTo(f32) -> GaussianBlur -> resize   (h_k, w_k) */
+int mav_stage_blur_resize(mav_ctx*, const uint8_t* img, int k, float* out);
+/* FarnebackPolyExp of a (h, w) f32 image at layer k -> R as 5 planes (5, h, w) */
+int mav_stage_polyexp(mav_ctx*, const float* I, int k, float* R);
+/* FarnebackUpdateMatrices at layer k: R0, R1 (5,h,w), flow (h,w,2) -> M (5,h,w) */
+int mav_stage_update_matrices(mav_ctx*, const float* R0, const float* R1, const float* flow, int k, float* M);
+/* one FarnebackUpdateFlow_Blur sweep at layer k: M (5,h,w) -> flow (h,w,2) and, if update != 0, M_out (5,h,w) */
+int mav_stage_blur_iter(mav_ctx*, const float* R0, const float* R1, const float* M, int k, int update, float* flow,
+                        float* M_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAVFLOW_H */

@@ -1,0 +1,438 @@
+// Detection kernels for gfx950: derotation, FoE candidates + RANSAC vote, phi + threshold masks + box, and the
+// small reductions around them.  Compiled with -ffp-contract=off: every double operation below is written in the
+// reference's numpy evaluation order so results are bit-identical to
+//   /root/reference/src/detector.py:70-117            (derotate)
+//   /root/reference/src/focus_of_expansion.py:32-86   (get_FOE_dense, ransac; utils.py:183-197 line_intersection)
+//   /root/reference/src/focus_of_expansion.py:150-184 (get_phi)
+//   /root/reference/src/processor.py:333-341          (threshold block)
+//   /root/reference/src/im_helpers.py:55-84,244-252   (get_simple_bounding_box, calculate_tpr_fpr)
+//   /root/reference/src/detector.py:280-312           (analyze_pyramid, level 0)
+// with one documented exception: arccos comes from the device math library, not the host's libm.
+#include "mavflow_internal.h"
+
+#include <limits.h>
+
+// Derotated flow vector at pixel (col, row) in double, reference operation order (detector.py:92-114).
+static __device__ __forceinline__ void flow_at(const float* __restrict__ flow, const DerotParams* __restrict__ dp, int W, int H,
+                                               int row, int col, double* fu, double* fv)
+{
+    const float2 f = *(const float2*)(flow + ((size_t)row * W + col) * 2);
+    double u = (double)f.x, v = (double)f.y;
+    if (dp && dp->enabled) {
+        const double x = -((double)col / (double)W - 0.5) * 2.0;
+        const double y = -((double)row / (double)H - 0.5) * 2.0;
+        const double o0 = dp->o0, o1 = dp->o1, o2 = dp->o2;
+        double du = (((o0 * x) * y - o1 * (x * x)) - o1) + o2 * y;
+        double dv = ((((-o2) * x + o0) + o0 * (y * y))) - (o1 * x) * y;
+        du = du * dp->sx;
+        dv = dv * dp->sy;
+        u = u - du;
+        v = v - dv;
+    }
+    *fu = u; *fv = v;
+}
+static __device__ __forceinline__ void flow_at(const double* __restrict__ flow, const DerotParams*, int W, int H, int row, int col,
+                                               double* fu, double* fv)
+{
+    const double2 f = *(const double2*)(flow + ((size_t)row * W + col) * 2);
+    *fu = f.x; *fv = f.y;
+}
+
+__global__ __launch_bounds__(256) void k_derotate(const float* __restrict__ flow, const DerotParams* __restrict__ derot, int W,
+                                                  int H, double* __restrict__ out)
+{
+    const int b = blockIdx.z;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const size_t img = (size_t)W * H * 2;
+    double u, v;
+    flow_at(flow + b * img, derot + b, W, H, y, x, &u, &v);
+    *(double2*)(out + b * img + ((size_t)y * W + x) * 2) = make_double2(u, v);
+}
+
+void launch_derotate(hipStream_t st, const float* flow, const DerotParams* derot, int B, int W, int H, double* out)
+{
+    dim3 grid((W + 63) / 64, (H + 3) / 4, B);
+    hipLaunchKernelGGL(k_derotate, grid, dim3(256), 0, st, flow, derot, W, H, out);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// FoE candidates: one 1024-thread workgroup per pair.  Thread i intersects the flow lines through samples i and
+// i+N; surviving rows (x != 0.0) are compacted IN INDEX ORDER (ballot + wave prefix) because RANSAC's tie-break
+// is "first candidate wins".
+// ------------------------------------------------------------------------------------------------------------
+template <typename FlowT>
+__global__ __launch_bounds__(1024) void k_foe_candidates(const FlowT* __restrict__ flow, const DerotParams* __restrict__ derot,
+                                                         const uint32_t* __restrict__ samples, int W, int H, int N,
+                                                         double mag2_thr, FoeScratch sc)
+{
+    __shared__ int wave_tot[16];
+    __shared__ int base_s;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const size_t img = (size_t)W * H * 2;
+    const FlowT* fl = flow + b * img;
+    const DerotParams* dp = derot ? derot + b : nullptr;
+    const uint32_t* smp = samples + (size_t)b * 4 * N;
+    double* cand = sc.cand + (size_t)b * 2 * N;
+    if (tid == 0) { base_s = 0; sc.best_key[b] = 0ull; }
+    __syncthreads();
+    for (int i0 = 0; i0 < N; i0 += 1024) {
+        const int i = i0 + tid;
+        bool keep = false;
+        double ix = 0.0, iy = 0.0;
+        if (i < N) {
+            const uint32_t r1 = smp[2 * i], c1 = smp[2 * i + 1];
+            const uint32_t r2 = smp[2 * (i + N)], c2 = smp[2 * (i + N) + 1];
+            if (r1 < (uint32_t)H && r2 < (uint32_t)H && c1 < (uint32_t)W && c2 < (uint32_t)W) {
+                double f1x, f1y, f2x, f2y;
+                flow_at(fl, dp, W, H, (int)r1, (int)c1, &f1x, &f1y);
+                flow_at(fl, dp, W, H, (int)r2, (int)c2, &f2x, &f2y);
+                const double mag2 = f2x * f2x + f2y * f2y;
+                if (!(mag2 < mag2_thr)) {  // == !(sqrt(mag2) < mag_threshold), see sq_threshold() on the host
+                    const double p1x = (double)c1, p1y = (double)r1, p2x = (double)c2, p2y = (double)r2;
+                    const double q1x = f1x + p1x, q1y = f1y + p1y, q2x = f2x + p2x, q2y = f2y + p2y;
+                    const double xd0 = p1x - q1x, xd1 = p2x - q2x, yd0 = p1y - q1y, yd1 = p2y - q2y;
+                    const double div = xd0 * yd1 - xd1 * yd0;
+                    if (!(div == 0.0)) {
+                        const double d0 = p1x * q1y - p1y * q1x;
+                        const double d1 = p2x * q2y - p2y * q2x;
+                        ix = (d0 * xd1 - d1 * xd0) / div;
+                        iy = (d0 * yd1 - d1 * yd0) / div;
+                        keep = (ix != 0.0);
+                    }
+                }
+            }
+        }
+        const unsigned long long bal = __ballot(keep);
+        const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[wv] = __popcll(bal);
+        __syncthreads();
+        int off = base_s;
+        for (int k = 0; k < wv; k++) off += wave_tot[k];
+        if (keep) {
+            cand[2 * (off + pre)] = ix;
+            cand[2 * (off + pre) + 1] = iy;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0;
+            for (int k = 0; k < 16; k++) t += wave_tot[k];
+            base_s += t;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) sc.count[b] = base_s;
+}
+
+// RANSAC vote: score_i = #{j : |e_j - e_i| < r} - 1; winner = largest score, lowest index (strict > in the loop).
+// Grid (ceil(N/256), B): each workgroup holds all candidates of its pair in LDS and scores 256 of them.
+__global__ __launch_bounds__(256) void k_ransac(FoeScratch sc, int N, double dist2_thr)
+{
+    extern __shared__ __attribute__((aligned(16))) double2 e[];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int M = sc.count[b];
+    if ((int)(blockIdx.x * 256) >= M) return;
+    const double2* cand = (const double2*)(sc.cand + (size_t)b * 2 * N);
+    for (int j = tid; j < M; j += 256) e[j] = cand[j];
+    __syncthreads();
+    const int i = blockIdx.x * 256 + tid;
+    unsigned long long key = 0ull;
+    if (i < M) {
+        const double2 ei = e[i];
+        int cnt = 0;
+        for (int j = 0; j < M; j++) {
+            const double dx = e[j].x - ei.x, dy = e[j].y - ei.y;
+            const double d2 = dx * dx + dy * dy;
+            cnt += (d2 < dist2_thr) ? 1 : 0;  // == (sqrt(d2) < ransac_threshold)
+        }
+        const int score = cnt - 1;
+        if (score > 0) key = ((unsigned long long)(unsigned)score << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(key, o);
+        key = other > key ? other : key;
+    }
+    if ((tid & 63) == 0 && key) atomicMax(&sc.best_key[b], key);
+}
+
+__global__ void k_foe_finalize(FoeScratch sc, int N, int B, double* __restrict__ foe)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const unsigned long long key = sc.best_key[b];
+    double x = 0.0, y = 0.0;
+    if (key) {
+        const unsigned idx = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
+        x = sc.cand[(size_t)b * 2 * N + 2 * idx];
+        y = sc.cand[(size_t)b * 2 * N + 2 * idx + 1];
+    }
+    foe[2 * b] = x;
+    foe[2 * b + 1] = y;
+}
+
+template <typename FlowT>
+static void launch_foe_t(hipStream_t st, const FlowT* flow, const DerotParams* derot, const uint32_t* samples, int B, int W,
+                         int H, int N, double mag2_thr, double dist2_thr, FoeScratch s, double* foe)
+{
+    hipLaunchKernelGGL(k_foe_candidates<FlowT>, dim3(B), dim3(1024), 0, st, flow, derot, samples, W, H, N, mag2_thr, s);
+    hipLaunchKernelGGL(k_ransac, dim3((N + 255) / 256, B), dim3(256), sizeof(double2) * (size_t)N, st, s, N, dist2_thr);
+    hipLaunchKernelGGL(k_foe_finalize, dim3((B + 63) / 64), dim3(64), 0, st, s, N, B, foe);
+}
+void launch_foe_f32(hipStream_t st, const float* flow, const DerotParams* derot, const uint32_t* samples, int B, int W, int H,
+                    int N, double mag2_thr, double dist2_thr, FoeScratch s, double* foe)
+{
+    launch_foe_t<float>(st, flow, derot, samples, B, W, H, N, mag2_thr, dist2_thr, s, foe);
+}
+void launch_foe_f64(hipStream_t st, const double* flow, const uint32_t* samples, int B, int W, int H, int N, double mag2_thr,
+                    double dist2_thr, FoeScratch s, double* foe)
+{
+    launch_foe_t<double>(st, flow, nullptr, samples, B, W, H, N, mag2_thr, dist2_thr, s, foe);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// phi + both threshold masks + box extents + max(phi), one pass over the flow.  Workgroup = 4 rows x 256 columns,
+// lane-contiguous float2/double2 loads; box extents and max(phi) are reduced per wave, then one atomic per wave.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void k_box_init(int32_t* box_acc, unsigned long long* max_phi_bits, int B)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    box_acc[4 * b] = INT_MAX; box_acc[4 * b + 1] = INT_MAX; box_acc[4 * b + 2] = -1; box_acc[4 * b + 3] = -1;
+    if (max_phi_bits) max_phi_bits[b] = 0ull;
+}
+void launch_box_init(hipStream_t st, int32_t* box_acc, unsigned long long* max_phi_bits, int B)
+{
+    hipLaunchKernelGGL(k_box_init, dim3((B + 63) / 64), dim3(64), 0, st, box_acc, max_phi_bits, B);
+}
+
+static __device__ __forceinline__ void wave_box_commit(int x0, int y0, int x1, int y1, int32_t* acc)
+{
+    for (int o = 32; o > 0; o >>= 1) {
+        x0 = min(x0, __shfl_xor(x0, o)); y0 = min(y0, __shfl_xor(y0, o));
+        x1 = max(x1, __shfl_xor(x1, o)); y1 = max(y1, __shfl_xor(y1, o));
+    }
+    if ((threadIdx.x & 63) == 0 && x1 >= 0) {
+        atomicMin(&acc[0], x0); atomicMin(&acc[1], y0); atomicMax(&acc[2], x1); atomicMax(&acc[3], y1);
+    }
+}
+
+template <typename FlowT>
+__global__ __launch_bounds__(256) void k_phi_mask(const FlowT* __restrict__ flow, const DerotParams* __restrict__ derot,
+                                                  const double* __restrict__ foe, const uint8_t* __restrict__ sky, int W, int H,
+                                                  mav_thr_params thr, double* __restrict__ phi_out, uint8_t* __restrict__ mfix,
+                                                  uint8_t* __restrict__ mdyn, int32_t* __restrict__ box_acc,
+                                                  unsigned long long* __restrict__ max_phi_bits)
+{
+    const int b = blockIdx.z;
+    const int lane = threadIdx.x & 63;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const size_t npx = (size_t)W * H;
+    const FlowT* fl = flow + b * npx * 2;
+    const DerotParams* dp = derot ? derot + b : nullptr;
+    const double foex = foe[2 * b], foey = foe[2 * b + 1];
+    int bx0 = INT_MAX, by0 = INT_MAX, bx1 = -1, by1 = -1;
+    double pmax = 0.0;
+    if (y < H) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int x = blockIdx.x * 256 + j * 64 + lane;
+            if (x >= W) continue;
+            double u, v;
+            flow_at(fl, dp, W, H, y, x, &u, &v);
+            const double d2x = (double)x - foex, d2y = (double)y - foey;
+            const double fm = sqrt(u * u + v * v);
+            const double dist = sqrt(d2x * d2x + d2y * d2y);
+            const double prod = fm * dist;
+            const double norm = (prod > 1e-6 || prod != prod) ? prod : 1e-6;  // np.maximum propagates NaN
+            double arg = (u * d2x + v * d2y) / norm;
+            double ph;
+            if (arg != arg) {
+                ph = 0.0;  // angle_diff[isnan] = 0
+            } else {
+                arg = arg < -1.0 ? -1.0 : (arg > 1.0 ? 1.0 : arg);
+                ph = acos(arg) * (180.0 / 3.141592653589793238462643383279502884);
+            }
+            const size_t o = b * npx + (size_t)y * W + x;
+            const bool notsky = sky ? (sky[o] == 0) : true;
+            const double t = thr.dyn_b + thr.dyn_c / fm;
+            const bool hi = ph > (thr.dyn_a + t);
+            const bool lo = ph < (thr.dyn_a - t);
+            const bool dyn = (fm > thr.dyn_min_mag) && notsky && (lo || hi);
+            const double gated = ((fm > thr.fixed_min_mag) && notsky) ? ph : 0.0;
+            const bool fix = gated > thr.fixed_deg;
+            if (phi_out) phi_out[o] = ph;
+            if (mfix) mfix[o] = fix ? 1 : 0;
+            if (mdyn) mdyn[o] = dyn ? 1 : 0;
+            if (fix) { bx0 = min(bx0, x); bx1 = max(bx1, x); by0 = min(by0, y); by1 = max(by1, y); }
+            pmax = ph > pmax ? ph : pmax;
+        }
+    }
+    wave_box_commit(bx0, by0, bx1, by1, box_acc + 4 * b);
+    if (max_phi_bits) {
+        unsigned long long bits = (unsigned long long)__double_as_longlong(pmax);  // phi >= 0: bit order == value order
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(bits, o);
+            bits = other > bits ? other : bits;
+        }
+        if (lane == 0 && bits) atomicMax(&max_phi_bits[b], bits);
+    }
+}
+
+void launch_phi_mask_f32(hipStream_t st, const float* flow, const DerotParams* derot, const double* foe, const uint8_t* sky,
+                         int B, int W, int H, mav_thr_params thr, double* phi, uint8_t* mask_fixed, uint8_t* mask_dyn,
+                         int32_t* box_acc, unsigned long long* max_phi_bits)
+{
+    dim3 grid((W + 255) / 256, (H + 3) / 4, B);
+    hipLaunchKernelGGL(k_phi_mask<float>, grid, dim3(256), 0, st, flow, derot, foe, sky, W, H, thr, phi, mask_fixed, mask_dyn,
+                       box_acc, max_phi_bits);
+}
+void launch_phi_mask_f64(hipStream_t st, const double* flow, const double* foe, const uint8_t* sky, int B, int W, int H,
+                         mav_thr_params thr, double* phi, uint8_t* mask_fixed, uint8_t* mask_dyn, int32_t* box_acc,
+                         unsigned long long* max_phi_bits)
+{
+    dim3 grid((W + 255) / 256, (H + 3) / 4, B);
+    hipLaunchKernelGGL(k_phi_mask<double>, grid, dim3(256), 0, st, flow, (const DerotParams*)nullptr, foe, sky, W, H, thr, phi,
+                       mask_fixed, mask_dyn, box_acc, max_phi_bits);
+}
+
+__global__ void k_finalize(const int32_t* __restrict__ box_acc, const double* __restrict__ foe, int B, mav_result* __restrict__ res,
+                           int32_t* __restrict__ box_only)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int x0 = box_acc[4 * b], y0 = box_acc[4 * b + 1], x1 = box_acc[4 * b + 2], y1 = box_acc[4 * b + 3];
+    if (x1 < 0) { x0 = y0 = x1 = y1 = -1; }
+    if (res) {
+        res[b].box[0] = x0; res[b].box[1] = y0; res[b].box[2] = x1; res[b].box[3] = y1;
+        res[b].foe[0] = foe[2 * b]; res[b].foe[1] = foe[2 * b + 1];
+    }
+    if (box_only) { box_only[4 * b] = x0; box_only[4 * b + 1] = y0; box_only[4 * b + 2] = x1; box_only[4 * b + 3] = y1; }
+}
+void launch_finalize(hipStream_t st, const int32_t* box_acc, const double* foe, int B, mav_result* results)
+{
+    hipLaunchKernelGGL(k_finalize, dim3((B + 63) / 64), dim3(64), 0, st, box_acc, foe, B, results, (int32_t*)nullptr);
+}
+void launch_box_finalize(hipStream_t st, const int32_t* box_acc, int B, int32_t* box)
+{
+    hipLaunchKernelGGL(k_finalize, dim3((B + 63) / 64), dim3(64), 0, st, box_acc, (const double*)nullptr, B,
+                       (mav_result*)nullptr, box);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// get_simple_bounding_box on arbitrary u8 images: pass 1 max, pass 2 extents of (double)v > 0.1*max.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_u8_max(const uint8_t* __restrict__ img, int W, int H, int* __restrict__ maxv)
+{
+    const int b = blockIdx.z;
+    const size_t npx = (size_t)W * H;
+    const uint8_t* p = img + b * npx;
+    int m = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npx; i += (size_t)gridDim.x * 256) m = max(m, (int)p[i]);
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(&maxv[b], m);
+}
+__global__ __launch_bounds__(256) void k_u8_extents(const uint8_t* __restrict__ img, int W, int H, const int* __restrict__ maxv,
+                                                    int32_t* __restrict__ box_acc)
+{
+    const int b = blockIdx.z;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const double thr = 0.1 * (double)maxv[b];
+    int bx0 = INT_MAX, by0 = INT_MAX, bx1 = -1, by1 = -1;
+    if (y < H)
+        for (int x = blockIdx.x * 256 + (threadIdx.x & 63); x < min(W, (int)(blockIdx.x + 1) * 256); x += 64)
+            if ((double)img[(size_t)b * W * H + (size_t)y * W + x] > thr) {
+                bx0 = min(bx0, x); bx1 = max(bx1, x); by0 = min(by0, y); by1 = max(by1, y);
+            }
+    wave_box_commit(bx0, by0, bx1, by1, box_acc + 4 * b);
+}
+void launch_bbox_u8(hipStream_t st, const uint8_t* img, int B, int W, int H, int* maxv, int32_t* box_acc)
+{
+    hipMemsetAsync(maxv, 0, sizeof(int) * B, st);
+    hipLaunchKernelGGL(k_u8_max, dim3(64, 1, B), dim3(256), 0, st, img, W, H, maxv);
+    hipLaunchKernelGGL(k_u8_extents, dim3((W + 255) / 256, (H + 3) / 4, B), dim3(256), 0, st, img, W, H, maxv, box_acc);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// analyze_pyramid level 0: 64x64 windows, stride 16, score = 3 * sum(u8) (the to_rgb replica has 3 equal channels);
+// first window in row-major scan order with the strictly largest score.  One workgroup per window row.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_window_max(const uint8_t* __restrict__ img, int W, int H, int nwx,
+                                                    unsigned long long* __restrict__ key)
+{
+    extern __shared__ int colsum[];
+    const int b = blockIdx.y, wy = blockIdx.x, tid = threadIdx.x;
+    const uint8_t* p = img + (size_t)b * W * H + (size_t)wy * 16 * W;
+    for (int x = tid; x < W; x += 256) {
+        int s = 0;
+        for (int r = 0; r < 64; r++) s += p[(size_t)r * W + x];
+        colsum[x] = s;
+    }
+    __syncthreads();
+    unsigned long long k = 0ull;
+    for (int wx = tid; wx < nwx; wx += 256) {
+        int s = 0;
+        for (int c = 0; c < 64; c++) s += colsum[wx * 16 + c];
+        const unsigned score = 3u * (unsigned)s;
+        const unsigned idx = (unsigned)(wy * nwx + wx);
+        if (score) {
+            const unsigned long long kk = ((unsigned long long)score << 32) | (0xFFFFFFFFu - idx);
+            k = kk > k ? kk : k;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(k, o);
+        k = other > k ? other : k;
+    }
+    if ((tid & 63) == 0 && k) atomicMax(&key[b], k);
+}
+__global__ void k_window_finalize(const unsigned long long* __restrict__ key, int nwx, int B, int64_t* __restrict__ out)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const unsigned long long k = key[b];
+    int64_t score = 0, x = 0, y = 0;
+    if (k) {
+        const unsigned idx = 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull);
+        score = (int64_t)(k >> 32);
+        x = (int64_t)(idx % nwx) * 16;
+        y = (int64_t)(idx / nwx) * 16;
+    }
+    out[3 * b] = score; out[3 * b + 1] = x; out[3 * b + 2] = y;
+}
+void launch_window_max(hipStream_t st, const uint8_t* img, int B, int W, int H, unsigned long long* key, int64_t* out)
+{
+    hipMemsetAsync(key, 0, sizeof(unsigned long long) * B, st);
+    const int nwx = W >= 64 ? (W - 64) / 16 + 1 : 0, nwy = H >= 64 ? (H - 64) / 16 + 1 : 0;
+    if (nwx > 0 && nwy > 0)
+        hipLaunchKernelGGL(k_window_max, dim3(nwy, B), dim3(256), sizeof(int) * (size_t)W, st, img, W, H, nwx, key);
+    hipLaunchKernelGGL(k_window_finalize, dim3((B + 63) / 64), dim3(64), 0, st, key, nwx > 0 ? nwx : 1, B, out);
+}
+
+// calculate_tpr_fpr counts for gt (u8) against 255*mask (mask 0/1): see the header for the integer identities.
+__global__ __launch_bounds__(256) void k_tpr_fpr(const uint8_t* __restrict__ gt, const uint8_t* __restrict__ mask, size_t npx,
+                                                 unsigned long long* __restrict__ counts)
+{
+    const int b = blockIdx.y;
+    const uint8_t* g = gt + b * npx;
+    const uint8_t* m = mask + b * npx;
+    unsigned pos = 0, neg = 0, tp = 0, fp = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npx; i += (size_t)gridDim.x * 256) {
+        const unsigned gv = g[i], mv = m[i] ? 255u : 0u;
+        pos += gv > 127u;
+        neg += (255u - gv) > 127u;
+        tp += (gv * mv) > 127u;
+        fp += ((255u - gv) * mv) > 127u;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        pos += __shfl_xor(pos, o); neg += __shfl_xor(neg, o); tp += __shfl_xor(tp, o); fp += __shfl_xor(fp, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&counts[4 * b], (unsigned long long)pos); atomicAdd(&counts[4 * b + 1], (unsigned long long)neg);
+        atomicAdd(&counts[4 * b + 2], (unsigned long long)tp); atomicAdd(&counts[4 * b + 3], (unsigned long long)fp);
+    }
+}
+void launch_tpr_fpr(hipStream_t st, const uint8_t* gt, const uint8_t* mask, int B, int W, int H, unsigned long long* counts)
+{
+    hipMemsetAsync(counts, 0, sizeof(unsigned long long) * 4 * B, st);
+    hipLaunchKernelGGL(k_tpr_fpr, dim3(128, B), dim3(256), 0, st, gt, mask, (size_t)W * H, counts);
+}

@@ -1,0 +1,906 @@
+// Host side of libmavflow.so: the C-ABI of include/mavflow.h over the gfx950 kernels.
+// Owns the context (stream, pyramid tables, workspace), schedules the per-layer launches in groups of pairs that
+// keep the iteration working set cache-sized, and maps every failure to an error code + message.
+#include <dlfcn.h>
+#include <math.h>
+#include <float.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "mavflow_internal.h"
+
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(call)                                                                                        \
+    do {                                                                                                    \
+        hipError_t e_ = (call);                                                                             \
+        if (e_ != hipSuccess)                                                                               \
+            return fail(e_ == hipErrorOutOfMemory ? MAV_ERR_OOM : MAV_ERR_HIP, "%s failed: %s (%s:%d)", #call, \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                                         \
+    } while (0)
+#define CHK(call)              \
+    do {                       \
+        int rc_ = (call);      \
+        if (rc_ != MAV_OK) return rc_; \
+    } while (0)
+
+extern "C" const char* mav_last_error(void) { return g_err.c_str(); }
+
+extern "C" void mav_fb_defaults(mav_fb_params* p) { *p = mav_fb_params{0.4, 1, 12, 10, 8, 1.2, 0}; }
+extern "C" void mav_foe_defaults(mav_foe_params* p) { *p = mav_foe_params{1000, 2.5, 30.0}; }
+extern "C" void mav_thr_defaults(mav_thr_params* p) { *p = mav_thr_params{15.0, 1.0, 0.5, 0.25, 0.5, 8.0}; }
+
+extern "C" int mav_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ---- small host math ------------------------------------------------------------------------------------
+static int cv_round(double v) { return (int)nearbyint(v); }
+static int reflect101(int p, int len)
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
+    return p;
+}
+// smallest double T with fl(sqrt(T)) >= t, so that  sqrt(v) < t  <=>  v < T  for every double v (sqrt is monotone
+// and correctly rounded on both sides).  Lets the kernels compare squared magnitudes without changing a single result.
+static double sq_threshold(double t)
+{
+    if (!(t > 0)) return 0.0;
+    double T = t * t;
+    while (sqrt(nextafter(T, -INFINITY)) >= t) T = nextafter(T, -INFINITY);
+    while (sqrt(T) < t) T = nextafter(T, INFINITY);
+    return T;
+}
+
+static void gaussian_kernel(int n, double sigma, std::vector<float>& k)  // getGaussianKernel(n, sigma, CV_32F)
+{
+    static const float small_tab[4][7] = {{1.f},
+                                          {0.25f, 0.5f, 0.25f},
+                                          {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f},
+                                          {0.03125f, 0.109375f, 0.21875f, 0.28125f, 0.21875f, 0.109375f, 0.03125f}};
+    const float* fixed = (n % 2 == 1 && n <= 7 && sigma <= 0) ? small_tab[n >> 1] : nullptr;
+    const double sx = sigma > 0 ? sigma : ((n - 1) * 0.5 - 1) * 0.3 + 0.8;
+    const double s2 = -0.5 / (sx * sx);
+    k.resize(n);
+    double sum = 0;
+    for (int i = 0; i < n; i++) {
+        const double x = i - (n - 1) * 0.5;
+        const double t = fixed ? (double)fixed[i] : exp(s2 * x * x);
+        k[i] = (float)t;
+        sum += k[i];
+    }
+    sum = 1. / sum;
+    for (int i = 0; i < n; i++) k[i] = (float)(k[i] * sum);
+}
+
+// 1-D tap table of "Gaussian blur (REFLECT_101) then linear resize (half-pixel centres, clamped)" along one axis.
+static void build_axis_table(int S, int d, int ksize, const std::vector<float>& g, std::vector<int>& idx, std::vector<float>& wt)
+{
+    const int taps = ksize + 1, r = ksize / 2;
+    idx.assign((size_t)d * taps, 0);
+    wt.assign((size_t)d * taps, 0.f);
+    const double scale = (double)S / d;
+    for (int o = 0; o < d; o++) {
+        int s0;
+        float f;
+        if (d == S) { s0 = o; f = 0.f; }
+        else {
+            f = (float)((o + 0.5) * scale - 0.5);
+            s0 = (int)floorf(f);
+            f -= s0;
+            if (s0 < 0) { f = 0.f; s0 = 0; }
+            if (s0 >= S - 1) { f = 0.f; s0 = S - 1; }
+        }
+        const float a0 = 1.f - f, a1 = f;
+        for (int t = 0; t < taps; t++) {
+            const int col = s0 - r + t;  // tap t of B[s0] and tap t-1 of B[s0+1] read the same source column
+            float wgt = 0.f;
+            if (t < ksize) wgt += a0 * g[t];
+            if (t >= 1) wgt += a1 * g[t - 1];
+            idx[(size_t)o * taps + t] = reflect101(col, S);
+            wt[(size_t)o * taps + t] = wgt;
+        }
+    }
+}
+
+static bool inv6_cholesky(const double G[36], double inv[36])
+{
+    double L[36];
+    memset(L, 0, sizeof(L));
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j <= i; j++) {
+            double s = G[i * 6 + j];
+            for (int k = 0; k < j; k++) s -= L[i * 6 + k] * L[j * 6 + k];
+            if (i == j) {
+                if (!(s > 0)) return false;
+                L[i * 6 + j] = sqrt(s);
+            } else
+                L[i * 6 + j] = s / L[j * 6 + j];
+        }
+    for (int c = 0; c < 6; c++) {
+        double y[6], x[6];
+        for (int i = 0; i < 6; i++) {
+            double s = (i == c) ? 1.0 : 0.0;
+            for (int k = 0; k < i; k++) s -= L[i * 6 + k] * y[k];
+            y[i] = s / L[i * 6 + i];
+        }
+        for (int i = 5; i >= 0; i--) {
+            double s = y[i];
+            for (int k = i + 1; k < 6; k++) s -= L[k * 6 + i] * x[k];
+            x[i] = s / L[i * 6 + i];
+        }
+        for (int i = 0; i < 6; i++) inv[i * 6 + c] = x[i];
+    }
+    return true;
+}
+
+static bool prepare_poly(int n, double sigma, PolyCoef* pc)  // FarnebackPrepareGaussian
+{
+    if (sigma < FLT_EPSILON) sigma = n * 0.3;
+    std::vector<float> gb(2 * n + 1), xgb(2 * n + 1), xxgb(2 * n + 1);
+    float *g = gb.data() + n, *xg = xgb.data() + n, *xxg = xxgb.data() + n;
+    double s = 0.;
+    for (int x = -n; x <= n; x++) {
+        g[x] = (float)exp(-x * x / (2 * sigma * sigma));
+        s += g[x];
+    }
+    s = 1. / s;
+    for (int x = -n; x <= n; x++) {
+        g[x] = (float)(g[x] * s);
+        xg[x] = (float)(x * g[x]);
+        xxg[x] = (float)(x * x * g[x]);
+    }
+    double G[36];
+    memset(G, 0, sizeof(G));
+    for (int y = -n; y <= n; y++)
+        for (int x = -n; x <= n; x++) {
+            G[0] += g[y] * g[x];
+            G[7] += g[y] * g[x] * x * x;
+            G[21] += g[y] * g[x] * x * x * x * x;
+            G[35] += g[y] * g[x] * x * x * y * y;
+        }
+    G[14] = G[3] = G[4] = G[18] = G[24] = G[7];
+    G[28] = G[21];
+    G[22] = G[27] = G[35];
+    double inv[36];
+    if (!inv6_cholesky(G, inv)) return false;
+    pc->n = n;
+    for (int k = 0; k <= n; k++) { pc->g[k] = g[k]; pc->xg[k] = xg[k]; pc->xxg[k] = xxg[k]; }
+    pc->ig11 = (float)inv[7]; pc->ig03 = (float)inv[3]; pc->ig33 = (float)inv[21]; pc->ig55 = (float)inv[35];
+    return true;
+}
+
+// ---- context -------------------------------------------------------------------------------------------
+struct Layer {
+    int w, h, ksize;
+    double sigma;
+    int *xi = nullptr, *yi = nullptr;
+    float *xw = nullptr, *yw = nullptr;
+};
+
+enum KernelId { K_BLUR_RESIZE, K_POLYEXP, K_UPDATE, K_ITER, K_FOE, K_PHI, K_MISC, K_COUNT };
+static const char* const kKernelNames[K_COUNT] = {"blur_resize", "polyexp", "update_matrices", "blur_iter",
+                                                  "foe_ransac", "phi_mask_box", "misc"};
+struct ProfRec { int kid; hipEvent_t a, b; };
+
+struct mav_ctx {
+    int device = 0, W = 0, H = 0, max_batch = 0, group = 0;
+    mav_fb_params fb;
+    hipStream_t stream = nullptr;
+    std::vector<Layer> layers;
+    PolyCoef pc;
+    // workspace (group slots)
+    size_t n0 = 0, n1 = 0;
+    float *I = nullptr, *R0 = nullptr, *R1 = nullptr, *Ma = nullptr, *Mb = nullptr, *fc[2] = {nullptr, nullptr};
+    float* flow_ws = nullptr;      // lazily allocated (max_batch) when the caller does not want the flow
+    // detection scratch (max_batch)
+    FoeScratch foe_sc{nullptr, nullptr, nullptr};
+    int foe_sc_n = 0;
+    double* foe_dev = nullptr;
+    int32_t* box_acc = nullptr;
+    unsigned long long* u64_scratch = nullptr;  // [max_batch*4]
+    int* i32_scratch = nullptr;                 // [max_batch]
+    DerotParams* derot_dev = nullptr;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    bool profiling = false;
+    std::vector<ProfRec> prof;
+    double prof_ms[K_COUNT] = {0};
+    long prof_n[K_COUNT] = {0};
+};
+
+struct ProfScope {
+    mav_ctx* c; int kid; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(mav_ctx* c_, int k) : c(c_), kid(k)
+    {
+        if (c->profiling) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, c->stream); }
+    }
+    ~ProfScope()
+    {
+        if (c->profiling) { hipEventRecord(b, c->stream); c->prof.push_back({kid, a, b}); }
+    }
+};
+
+static void free_layer(Layer& l)
+{
+    if (l.xi) hipFree(l.xi); if (l.yi) hipFree(l.yi); if (l.xw) hipFree(l.xw); if (l.yw) hipFree(l.yw);
+    l.xi = l.yi = nullptr; l.xw = l.yw = nullptr;
+}
+
+static int alloc_group(mav_ctx* c, int group)
+{
+    float** bufs[] = {&c->I, &c->R0, &c->R1, &c->Ma, &c->Mb, &c->fc[0], &c->fc[1]};
+    for (auto b : bufs) { if (*b) hipFree(*b); *b = nullptr; }
+    c->group = group;
+    const size_t g = (size_t)group;
+    HIPCHK(hipMalloc(&c->I, sizeof(float) * c->n0 * g));
+    HIPCHK(hipMalloc(&c->R0, sizeof(float) * 5 * c->n0 * g));
+    HIPCHK(hipMalloc(&c->R1, sizeof(float) * 5 * c->n0 * g));
+    HIPCHK(hipMalloc(&c->Ma, sizeof(float) * 5 * c->n0 * g));
+    HIPCHK(hipMalloc(&c->Mb, sizeof(float) * 5 * c->n0 * g));
+    HIPCHK(hipMalloc(&c->fc[0], sizeof(float) * 2 * (c->n1 ? c->n1 : 1) * g));
+    HIPCHK(hipMalloc(&c->fc[1], sizeof(float) * 2 * (c->n1 ? c->n1 : 1) * g));
+    return MAV_OK;
+}
+
+extern "C" int mav_destroy(mav_ctx* c)
+{
+    if (!c) return MAV_OK;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (auto& l : c->layers) free_layer(l);
+    void* bufs[] = {c->I, c->R0, c->R1, c->Ma, c->Mb, c->fc[0], c->fc[1], c->flow_ws, c->foe_sc.cand, c->foe_sc.count,
+                    c->foe_sc.best_key, c->foe_dev, c->box_acc, c->u64_scratch, c->i32_scratch, c->derot_dev};
+    for (void* b : bufs) if (b) hipFree(b);
+    for (auto& r : c->prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    if (c->t0) hipEventDestroy(c->t0);
+    if (c->t1) hipEventDestroy(c->t1);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return MAV_OK;
+}
+
+extern "C" int mav_create(mav_ctx** out, int device, int W, int H, int max_batch, const mav_fb_params* fbp)
+{
+    if (!out) return fail(MAV_ERR_ARG, "mav_create: out is NULL");
+    *out = nullptr;
+    mav_fb_params fb;
+    if (fbp) fb = *fbp; else mav_fb_defaults(&fb);
+    if (W < 1 || H < 1 || max_batch < 1) return fail(MAV_ERR_ARG, "mav_create: bad size W=%d H=%d max_batch=%d", W, H, max_batch);
+    if (!(fb.pyr_scale > 0 && fb.pyr_scale < 1)) return fail(MAV_ERR_ARG, "pyr_scale must be in (0, 1), got %g", fb.pyr_scale);
+    if (fb.levels < 0 || fb.winsize < 2 || fb.winsize > 64 || fb.iterations < 1 || fb.poly_n < 1 || fb.poly_n > MAV_MAX_POLY_N)
+        return fail(MAV_ERR_ARG, "unsupported Farneback parameters (levels=%d winsize=%d iterations=%d poly_n=%d)", fb.levels,
+                    fb.winsize, fb.iterations, fb.poly_n);
+    if (fb.flags != 0) return fail(MAV_ERR_ARG, "only flags == 0 (box window, no initial flow) is implemented, got %d", fb.flags);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(MAV_ERR_STATE, "no HIP device visible: libmavflow has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(MAV_ERR_ARG, "device %d out of range (%d visible)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+
+    mav_ctx* c = new mav_ctx();
+    c->device = device; c->W = W; c->H = H; c->max_batch = max_batch; c->fb = fb;
+    int rc = MAV_OK;
+    auto bail = [&](int code) { mav_destroy(c); return code; };
+#define HIPB(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fail(e_ == hipErrorOutOfMemory ? MAV_ERR_OOM : MAV_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); return bail(e_ == hipErrorOutOfMemory ? MAV_ERR_OOM : MAV_ERR_HIP); } } while (0)
+    HIPB(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPB(hipEventCreate(&c->t0));
+    HIPB(hipEventCreate(&c->t1));
+    if (!prepare_poly(fb.poly_n, fb.poly_sigma, &c->pc)) { fail(MAV_ERR_ARG, "poly_sigma %g gives a singular moment matrix", fb.poly_sigma); return bail(MAV_ERR_ARG); }
+
+    // layer selection exactly as optflowgf.cpp (A.1): levels is the number of EXTRA layers actually reachable
+    int levels = 0;
+    {
+        double scale = 1;
+        for (levels = 0; levels < fb.levels; levels++) {
+            scale *= fb.pyr_scale;
+            if (W * scale < 32 || H * scale < 32) break;
+        }
+    }
+    c->layers.resize(levels + 1);
+    for (int k = 0; k <= levels; k++) {
+        Layer& l = c->layers[k];
+        double scale = 1;
+        for (int i = 0; i < k; i++) scale *= fb.pyr_scale;
+        l.sigma = (1. / scale - 1) * 0.5;
+        l.ksize = cv_round(l.sigma * 5) | 1;
+        if (l.ksize < 3) l.ksize = 3;
+        l.w = cv_round(W * scale);
+        l.h = cv_round(H * scale);
+        if (l.w < 1 || l.h < 1) { fail(MAV_ERR_ARG, "layer %d collapses to %dx%d", k, l.w, l.h); return bail(MAV_ERR_ARG); }
+        std::vector<float> g;
+        gaussian_kernel(l.ksize, l.sigma, g);
+        std::vector<int> xi, yi;
+        std::vector<float> xw, yw;
+        build_axis_table(W, l.w, l.ksize, g, xi, xw);
+        build_axis_table(H, l.h, l.ksize, g, yi, yw);
+        HIPB(hipMalloc(&l.xi, xi.size() * sizeof(int)));
+        HIPB(hipMalloc(&l.xw, xw.size() * sizeof(float)));
+        HIPB(hipMalloc(&l.yi, yi.size() * sizeof(int)));
+        HIPB(hipMalloc(&l.yw, yw.size() * sizeof(float)));
+        HIPB(hipMemcpy(l.xi, xi.data(), xi.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPB(hipMemcpy(l.xw, xw.data(), xw.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIPB(hipMemcpy(l.yi, yi.data(), yi.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPB(hipMemcpy(l.yw, yw.data(), yw.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    c->n0 = (size_t)W * H;
+    c->n1 = levels >= 1 ? (size_t)c->layers[1].w * c->layers[1].h : 0;
+    // group: pairs per launch.  Default keeps ~2 pairs of the full-resolution iteration working set in flight; the
+    // caller can raise it with mav_set_option("group").
+    int group = max_batch < 2 ? max_batch : 2;
+    if (const char* e = getenv("MAVFLOW_GROUP")) { int v = atoi(e); if (v >= 1) group = v < max_batch ? v : max_batch; }
+    rc = alloc_group(c, group);
+    if (rc != MAV_OK) return bail(rc);
+    const size_t B = (size_t)max_batch;
+    HIPB(hipMalloc(&c->foe_dev, sizeof(double) * 2 * B));
+    HIPB(hipMalloc(&c->box_acc, sizeof(int32_t) * 4 * B));
+    HIPB(hipMalloc(&c->u64_scratch, sizeof(unsigned long long) * 4 * B));
+    HIPB(hipMalloc(&c->i32_scratch, sizeof(int) * B));
+    HIPB(hipMalloc(&c->derot_dev, sizeof(DerotParams) * B));
+    HIPB(hipMalloc(&c->foe_sc.count, sizeof(int) * B));
+    HIPB(hipMalloc(&c->foe_sc.best_key, sizeof(unsigned long long) * B));
+#undef HIPB
+    *out = c;
+    return MAV_OK;
+}
+
+extern "C" int mav_set_option(mav_ctx* c, const char* name, long value)
+{
+    if (!c || !name) return fail(MAV_ERR_ARG, "mav_set_option: NULL argument");
+    if (!strcmp(name, "group")) {
+        if (value < 1) return fail(MAV_ERR_ARG, "group must be >= 1");
+        int g = value > c->max_batch ? c->max_batch : (int)value;
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        return g == c->group ? MAV_OK : alloc_group(c, g);
+    }
+    return fail(MAV_ERR_ARG, "unknown option '%s'", name);
+}
+
+extern "C" int mav_num_layers(const mav_ctx* c) { return c ? (int)c->layers.size() : 0; }
+extern "C" int mav_layer_dims(const mav_ctx* c, int k, int* w, int* h, int* ksize, double* sigma)
+{
+    if (!c || k < 0 || k >= (int)c->layers.size()) return fail(MAV_ERR_ARG, "mav_layer_dims: bad layer %d", k);
+    if (w) *w = c->layers[k].w; if (h) *h = c->layers[k].h; if (ksize) *ksize = c->layers[k].ksize; if (sigma) *sigma = c->layers[k].sigma;
+    return MAV_OK;
+}
+
+extern "C" int mav_sync(mav_ctx* c)
+{
+    if (!c) return fail(MAV_ERR_ARG, "mav_sync: NULL context");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MAV_OK;
+}
+extern "C" void* mav_stream(mav_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+extern "C" int mav_dev_alloc(mav_ctx* c, size_t bytes, void** out)
+{
+    if (!c || !out) return fail(MAV_ERR_ARG, "mav_dev_alloc: NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMalloc(out, bytes ? bytes : 1));
+    return MAV_OK;
+}
+extern "C" int mav_dev_free(mav_ctx* c, void* p)
+{
+    if (!c) return fail(MAV_ERR_ARG, "mav_dev_free: NULL context");
+    if (p) HIPCHK(hipFree(p));
+    return MAV_OK;
+}
+extern "C" int mav_memcpy_h2d(mav_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    if (!c || !dst || !src) return fail(MAV_ERR_ARG, "mav_memcpy_h2d: NULL argument");
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MAV_OK;
+}
+extern "C" int mav_memcpy_d2h(mav_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    if (!c || !dst || !src) return fail(MAV_ERR_ARG, "mav_memcpy_d2h: NULL argument");
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MAV_OK;
+}
+
+extern "C" int mav_timer_start(mav_ctx* c)
+{
+    if (!c) return fail(MAV_ERR_ARG, "mav_timer_start: NULL context");
+    HIPCHK(hipEventRecord(c->t0, c->stream));
+    return MAV_OK;
+}
+extern "C" int mav_timer_stop(mav_ctx* c, float* ms)
+{
+    if (!c || !ms) return fail(MAV_ERR_ARG, "mav_timer_stop: NULL argument");
+    HIPCHK(hipEventRecord(c->t1, c->stream));
+    HIPCHK(hipEventSynchronize(c->t1));
+    HIPCHK(hipEventElapsedTime(ms, c->t0, c->t1));
+    return MAV_OK;
+}
+
+static int prof_collect(mav_ctx* c)
+{
+    if (c->prof.empty()) return MAV_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (auto& r : c->prof) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { c->prof_ms[r.kid] += ms; c->prof_n[r.kid]++; }
+        hipEventDestroy(r.a); hipEventDestroy(r.b);
+    }
+    c->prof.clear();
+    return MAV_OK;
+}
+extern "C" int mav_profile_enable(mav_ctx* c, int on)
+{
+    if (!c) return fail(MAV_ERR_ARG, "mav_profile_enable: NULL context");
+    CHK(prof_collect(c));
+    if (on) { memset(c->prof_ms, 0, sizeof(c->prof_ms)); memset(c->prof_n, 0, sizeof(c->prof_n)); }
+    c->profiling = on != 0;
+    return MAV_OK;
+}
+extern "C" int mav_profile_get(mav_ctx* c, int* n, const char** names, double* total_ms, long* launches)
+{
+    if (!c || !n) return fail(MAV_ERR_ARG, "mav_profile_get: NULL argument");
+    CHK(prof_collect(c));
+    int cap = *n, k = 0;
+    for (int i = 0; i < K_COUNT && k < cap; i++, k++) {
+        if (names) names[k] = kKernelNames[i];
+        if (total_ms) total_ms[k] = c->prof_ms[i];
+        if (launches) launches[k] = c->prof_n[i];
+    }
+    *n = k;
+    return MAV_OK;
+}
+
+static int check_launch(const char* what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MAV_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+    return MAV_OK;
+}
+
+// ---- Farneback pipeline ----------------------------------------------------------------------------------
+static ResizeTables tables_of(const Layer& l) { return ResizeTables{l.ksize + 1, l.xi, l.xw, l.yi, l.yw}; }
+
+static int farneback_group(mav_ctx* c, const uint8_t* prev, const uint8_t* next, int g, float* flow_out)
+{
+    const size_t n0 = c->n0;
+    const int L = (int)c->layers.size();
+    const float* flow_prev = nullptr;
+    int pw = 0, ph = 0;
+    const size_t fc_stride = 2 * (c->n1 ? c->n1 : 1);
+    for (int k = L - 1; k >= 0; k--) {
+        const Layer& l = c->layers[k];
+        const uint8_t* img[2] = {prev, next};
+        float* R[2] = {c->R0, c->R1};
+        for (int i = 0; i < 2; i++) {
+            { ProfScope ps(c, K_BLUR_RESIZE);
+              launch_blur_resize(c->stream, img[i], n0, g, c->W, c->H, l.w, l.h, tables_of(l), c->I, n0); }
+            { ProfScope ps(c, K_POLYEXP);
+              launch_polyexp(c->stream, c->I, n0, g, l.w, l.h, c->pc, R[i], 5 * n0); }
+        }
+        { ProfScope ps(c, K_UPDATE);
+          launch_update_matrices(c->stream, c->R0, c->R1, 5 * n0, flow_prev, fc_stride, pw, ph, (float)(1. / c->fb.pyr_scale), g,
+                                 l.w, l.h, c->Ma, 5 * n0); }
+        float* fdst = k > 0 ? c->fc[k & 1] : flow_out;
+        const size_t fstride = k > 0 ? fc_stride : 2 * n0;
+        float *Min = c->Ma, *Mout = c->Mb;
+        for (int it = 0; it < c->fb.iterations; it++) {
+            const int upd = it < c->fb.iterations - 1;
+            { ProfScope ps(c, K_ITER);
+              launch_blur_iter(c->stream, Min, Mout, 5 * n0, c->R0, c->R1, 5 * n0, g, l.w, l.h, c->fb.winsize, upd, fdst, fstride); }
+            if (upd) { float* t = Min; Min = Mout; Mout = t; }
+        }
+        flow_prev = fdst; pw = l.w; ph = l.h;
+    }
+    return check_launch("farneback kernels");
+}
+
+extern "C" int mav_farneback_dev(mav_ctx* c, const uint8_t* prev, const uint8_t* next, int batch, float* flow)
+{
+    if (!c || !prev || !next || !flow) return fail(MAV_ERR_ARG, "mav_farneback: NULL argument");
+    if (batch < 1 || batch > c->max_batch) return fail(MAV_ERR_ARG, "batch %d outside [1, %d]", batch, c->max_batch);
+    HIPCHK(hipSetDevice(c->device));
+    for (int g0 = 0; g0 < batch; g0 += c->group) {
+        const int g = batch - g0 < c->group ? batch - g0 : c->group;
+        CHK(farneback_group(c, prev + (size_t)g0 * c->n0, next + (size_t)g0 * c->n0, g, flow + (size_t)g0 * 2 * c->n0));
+    }
+    return MAV_OK;
+}
+
+// ---- detection ---------------------------------------------------------------------------------------------
+static int ensure_foe_scratch(mav_ctx* c, int N)
+{
+    if (N <= c->foe_sc_n) return MAV_OK;
+    if (c->foe_sc.cand) hipFree(c->foe_sc.cand);
+    c->foe_sc.cand = nullptr; c->foe_sc_n = 0;
+    HIPCHK(hipMalloc(&c->foe_sc.cand, sizeof(double) * 2 * (size_t)N * c->max_batch));
+    c->foe_sc_n = N;
+    return MAV_OK;
+}
+
+static int upload_derot(mav_ctx* c, const double* omega, const double* dt, int batch, bool host_ptrs, const DerotParams** out)
+{
+    *out = nullptr;
+    if (!omega) return MAV_OK;
+    std::vector<double> om(3 * (size_t)batch), dts((size_t)batch, 1.0);
+    if (host_ptrs) {
+        memcpy(om.data(), omega, sizeof(double) * 3 * batch);
+        if (dt) memcpy(dts.data(), dt, sizeof(double) * batch);
+    } else {
+        HIPCHK(hipMemcpyAsync(om.data(), omega, sizeof(double) * 3 * batch, hipMemcpyDeviceToHost, c->stream));
+        if (dt) HIPCHK(hipMemcpyAsync(dts.data(), dt, sizeof(double) * batch, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    std::vector<DerotParams> dp(batch);
+    for (int b = 0; b < batch; b++) {
+        dp[b].o0 = om[3 * b]; dp[b].o1 = om[3 * b + 1]; dp[b].o2 = om[3 * b + 2];
+        dp[b].sx = c->W * dts[b] / 2;   // w * dt / 2   (detector.py:101)
+        dp[b].sy = c->H * dts[b] / 2;
+        dp[b].enabled = 1;
+    }
+    HIPCHK(hipMemcpyAsync(c->derot_dev, dp.data(), sizeof(DerotParams) * batch, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));  // dp is a stack vector
+    *out = c->derot_dev;
+    return MAV_OK;
+}
+
+static int detect_dev(mav_ctx* c, const float* flow32, const double* flow64, const DerotParams* derot, const uint32_t* samples,
+                      const uint8_t* sky, int batch, const mav_foe_params* fp, const mav_thr_params* tp, const double* foe_in,
+                      double* phi, uint8_t* mask_fixed, uint8_t* mask_dyn, unsigned long long* max_phi_bits, double* foe_out,
+                      mav_result* results, int32_t* box_out)
+{
+    const int W = c->W, H = c->H;
+    const double* foe = foe_in;
+    if (samples) {
+        mav_foe_params f;
+        if (fp) f = *fp; else mav_foe_defaults(&f);
+        if (f.n_pairs < 1 || f.n_pairs > 4096) return fail(MAV_ERR_ARG, "n_pairs %d outside [1, 4096]", f.n_pairs);
+        CHK(ensure_foe_scratch(c, f.n_pairs));
+        double* fo = foe_out ? foe_out : c->foe_dev;
+        ProfScope ps(c, K_FOE);
+        if (flow32)
+            launch_foe_f32(c->stream, flow32, derot, samples, batch, W, H, f.n_pairs, sq_threshold(f.mag_threshold),
+                           sq_threshold(f.ransac_threshold), c->foe_sc, fo);
+        else
+            launch_foe_f64(c->stream, flow64, samples, batch, W, H, f.n_pairs, sq_threshold(f.mag_threshold),
+                           sq_threshold(f.ransac_threshold), c->foe_sc, fo);
+        foe = fo;
+    }
+    if (tp || phi || mask_fixed || mask_dyn || results || box_out || max_phi_bits) {
+        if (!foe) return fail(MAV_ERR_ARG, "phi/mask stage needs a FoE (samples or foe)");
+        mav_thr_params t;
+        if (tp) t = *tp; else mav_thr_defaults(&t);
+        { ProfScope ps(c, K_MISC); launch_box_init(c->stream, c->box_acc, max_phi_bits, batch); }
+        { ProfScope ps(c, K_PHI);
+          if (flow32)
+              launch_phi_mask_f32(c->stream, flow32, derot, foe, sky, batch, W, H, t, phi, mask_fixed, mask_dyn, c->box_acc, max_phi_bits);
+          else
+              launch_phi_mask_f64(c->stream, flow64, foe, sky, batch, W, H, t, phi, mask_fixed, mask_dyn, c->box_acc, max_phi_bits); }
+        ProfScope ps(c, K_MISC);
+        if (results) launch_finalize(c->stream, c->box_acc, foe, batch, results);
+        if (box_out) launch_box_finalize(c->stream, c->box_acc, batch, box_out);
+    }
+    return check_launch("detection kernels");
+}
+
+extern "C" int mav_process_batch_dev(mav_ctx* c, const uint8_t* prev, const uint8_t* next, const uint32_t* samples,
+                                     const double* omega, const double* dt, const uint8_t* sky, int batch,
+                                     const mav_foe_params* fp, const mav_thr_params* tp, float* flow, double* phi,
+                                     uint8_t* mask_fixed, uint8_t* mask_dyn, mav_result* results)
+{
+    if (!c || !prev || !next || !samples || !results) return fail(MAV_ERR_ARG, "mav_process_batch: NULL argument");
+    if (batch < 1 || batch > c->max_batch) return fail(MAV_ERR_ARG, "batch %d outside [1, %d]", batch, c->max_batch);
+    HIPCHK(hipSetDevice(c->device));
+    if (!flow) {
+        if (!c->flow_ws) HIPCHK(hipMalloc(&c->flow_ws, sizeof(float) * 2 * c->n0 * c->max_batch));
+        flow = c->flow_ws;
+    }
+    const DerotParams* derot = nullptr;
+    CHK(upload_derot(c, omega, dt, batch, false, &derot));
+    CHK(mav_farneback_dev(c, prev, next, batch, flow));
+    mav_thr_params t;
+    if (tp) t = *tp; else mav_thr_defaults(&t);
+    return detect_dev(c, flow, nullptr, derot, samples, sky, batch, fp, &t, nullptr, phi, mask_fixed, mask_dyn, nullptr, nullptr,
+                      results, nullptr);
+}
+
+// ---- host-pointer wrappers -----------------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    int alloc(size_t bytes) { HIPCHK(hipMalloc(&p, bytes ? bytes : 1)); return MAV_OK; }
+    int upload(mav_ctx* c, const void* src, size_t bytes)
+    {
+        CHK(alloc(bytes));
+        HIPCHK(hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, c->stream));
+        return MAV_OK;
+    }
+    template <typename T> T* as() { return (T*)p; }
+};
+static int download(mav_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    return MAV_OK;
+}
+static int check_batch(mav_ctx* c, int batch, const char* fn)
+{
+    if (!c) return fail(MAV_ERR_ARG, "%s: NULL context", fn);
+    if (batch < 1 || batch > c->max_batch) return fail(MAV_ERR_ARG, "%s: batch %d outside [1, %d]", fn, batch, c->max_batch);
+    HIPCHK(hipSetDevice(c->device));
+    return MAV_OK;
+}
+
+extern "C" int mav_farneback(mav_ctx* c, const uint8_t* prev, const uint8_t* next, int batch, float* flow)
+{
+    CHK(check_batch(c, batch, "mav_farneback"));
+    if (!prev || !next || !flow) return fail(MAV_ERR_ARG, "mav_farneback: NULL argument");
+    const size_t n = c->n0 * batch;
+    DevBuf dp, dn, df;
+    CHK(dp.upload(c, prev, n)); CHK(dn.upload(c, next, n)); CHK(df.alloc(n * 2 * sizeof(float)));
+    CHK(mav_farneback_dev(c, dp.as<uint8_t>(), dn.as<uint8_t>(), batch, df.as<float>()));
+    CHK(download(c, flow, df.p, n * 2 * sizeof(float)));
+    return mav_sync(c);
+}
+
+extern "C" int mav_derotate(mav_ctx* c, const float* flow, const double* omega, const double* dt, int batch, double* flow_out)
+{
+    CHK(check_batch(c, batch, "mav_derotate"));
+    if (!flow || !omega || !flow_out) return fail(MAV_ERR_ARG, "mav_derotate: NULL argument");
+    const size_t n = c->n0 * batch * 2;
+    DevBuf df, dout;
+    CHK(df.upload(c, flow, n * sizeof(float))); CHK(dout.alloc(n * sizeof(double)));
+    const DerotParams* derot = nullptr;
+    CHK(upload_derot(c, omega, dt, batch, true, &derot));
+    launch_derotate(c->stream, df.as<float>(), derot, batch, c->W, c->H, dout.as<double>());
+    CHK(check_launch("derotate"));
+    CHK(download(c, flow_out, dout.p, n * sizeof(double)));
+    return mav_sync(c);
+}
+
+extern "C" int mav_foe_dense(mav_ctx* c, const double* flow, const uint32_t* samples, int batch, const mav_foe_params* fp, double* foe)
+{
+    CHK(check_batch(c, batch, "mav_foe_dense"));
+    if (!flow || !samples || !foe) return fail(MAV_ERR_ARG, "mav_foe_dense: NULL argument");
+    mav_foe_params f;
+    if (fp) f = *fp; else mav_foe_defaults(&f);
+    if (f.n_pairs < 1 || f.n_pairs > 4096) return fail(MAV_ERR_ARG, "n_pairs %d outside [1, 4096]", f.n_pairs);
+    DevBuf df, ds, dfoe;
+    CHK(df.upload(c, flow, c->n0 * batch * 2 * sizeof(double)));
+    CHK(ds.upload(c, samples, sizeof(uint32_t) * 4 * (size_t)f.n_pairs * batch));
+    CHK(dfoe.alloc(sizeof(double) * 2 * batch));
+    CHK(detect_dev(c, nullptr, df.as<double>(), nullptr, ds.as<uint32_t>(), nullptr, batch, &f, nullptr, nullptr, nullptr, nullptr,
+                   nullptr, nullptr, dfoe.as<double>(), nullptr, nullptr));
+    CHK(download(c, foe, dfoe.p, sizeof(double) * 2 * batch));
+    return mav_sync(c);
+}
+
+extern "C" int mav_phi_mask(mav_ctx* c, const double* flow, const double* foe, const uint8_t* sky, int batch, const mav_thr_params* tp,
+                            double* phi, uint8_t* mask_fixed, uint8_t* mask_dyn, double* max_phi)
+{
+    CHK(check_batch(c, batch, "mav_phi_mask"));
+    if (!flow || !foe) return fail(MAV_ERR_ARG, "mav_phi_mask: NULL argument");
+    const size_t n = c->n0 * batch;
+    mav_thr_params t;
+    if (tp) t = *tp; else mav_thr_defaults(&t);
+    DevBuf df, dfoe, dsky, dphi, dmf, dmd;
+    CHK(df.upload(c, flow, n * 2 * sizeof(double)));
+    CHK(dfoe.upload(c, foe, sizeof(double) * 2 * batch));
+    if (sky) CHK(dsky.upload(c, sky, n));
+    if (phi) CHK(dphi.alloc(n * sizeof(double)));
+    if (mask_fixed) CHK(dmf.alloc(n));
+    if (mask_dyn) CHK(dmd.alloc(n));
+    CHK(detect_dev(c, nullptr, df.as<double>(), nullptr, nullptr, dsky.as<uint8_t>(), batch, nullptr, &t, dfoe.as<double>(),
+                   dphi.as<double>(), dmf.as<uint8_t>(), dmd.as<uint8_t>(), max_phi ? c->u64_scratch : nullptr, nullptr, nullptr,
+                   nullptr));
+    if (phi) CHK(download(c, phi, dphi.p, n * sizeof(double)));
+    if (mask_fixed) CHK(download(c, mask_fixed, dmf.p, n));
+    if (mask_dyn) CHK(download(c, mask_dyn, dmd.p, n));
+    if (max_phi) CHK(download(c, max_phi, c->u64_scratch, sizeof(double) * batch));  // same bits
+    return mav_sync(c);
+}
+
+extern "C" int mav_bbox(mav_ctx* c, const uint8_t* img, int batch, int32_t* box)
+{
+    CHK(check_batch(c, batch, "mav_bbox"));
+    if (!img || !box) return fail(MAV_ERR_ARG, "mav_bbox: NULL argument");
+    DevBuf di, db;
+    CHK(di.upload(c, img, c->n0 * batch)); CHK(db.alloc(sizeof(int32_t) * 4 * batch));
+    launch_box_init(c->stream, c->box_acc, nullptr, batch);
+    launch_bbox_u8(c->stream, di.as<uint8_t>(), batch, c->W, c->H, c->i32_scratch, c->box_acc);
+    launch_box_finalize(c->stream, c->box_acc, batch, db.as<int32_t>());
+    CHK(check_launch("bbox"));
+    CHK(download(c, box, db.p, sizeof(int32_t) * 4 * batch));
+    return mav_sync(c);
+}
+
+extern "C" int mav_window_max(mav_ctx* c, const uint8_t* img, int batch, int64_t* out)
+{
+    CHK(check_batch(c, batch, "mav_window_max"));
+    if (!img || !out) return fail(MAV_ERR_ARG, "mav_window_max: NULL argument");
+    DevBuf di, dout;
+    CHK(di.upload(c, img, c->n0 * batch)); CHK(dout.alloc(sizeof(int64_t) * 3 * batch));
+    launch_window_max(c->stream, di.as<uint8_t>(), batch, c->W, c->H, c->u64_scratch, dout.as<int64_t>());
+    CHK(check_launch("window_max"));
+    CHK(download(c, out, dout.p, sizeof(int64_t) * 3 * batch));
+    return mav_sync(c);
+}
+
+extern "C" int mav_tpr_fpr_counts(mav_ctx* c, const uint8_t* gt, const uint8_t* mask, int batch, int64_t* counts)
+{
+    CHK(check_batch(c, batch, "mav_tpr_fpr_counts"));
+    if (!gt || !mask || !counts) return fail(MAV_ERR_ARG, "mav_tpr_fpr_counts: NULL argument");
+    DevBuf dg, dm;
+    CHK(dg.upload(c, gt, c->n0 * batch)); CHK(dm.upload(c, mask, c->n0 * batch));
+    launch_tpr_fpr(c->stream, dg.as<uint8_t>(), dm.as<uint8_t>(), batch, c->W, c->H, c->u64_scratch);
+    CHK(check_launch("tpr_fpr"));
+    CHK(download(c, counts, c->u64_scratch, sizeof(int64_t) * 4 * batch));
+    return mav_sync(c);
+}
+
+extern "C" int mav_process_batch(mav_ctx* c, const uint8_t* prev, const uint8_t* next, const uint32_t* samples, const double* omega,
+                                 const double* dt, const uint8_t* sky, int batch, const mav_foe_params* fp, const mav_thr_params* tp,
+                                 float* flow, double* phi, uint8_t* mask_fixed, uint8_t* mask_dyn, mav_result* results)
+{
+    CHK(check_batch(c, batch, "mav_process_batch"));
+    if (!prev || !next || !samples || !results) return fail(MAV_ERR_ARG, "mav_process_batch: NULL argument");
+    mav_foe_params f;
+    if (fp) f = *fp; else mav_foe_defaults(&f);
+    if (f.n_pairs < 1 || f.n_pairs > 4096) return fail(MAV_ERR_ARG, "n_pairs %d outside [1, 4096]", f.n_pairs);
+    const size_t n = c->n0 * batch;
+    DevBuf dp, dn, ds, dsky, dflow, dphi, dmf, dmd, dres, dom, ddt;
+    CHK(dp.upload(c, prev, n)); CHK(dn.upload(c, next, n));
+    CHK(ds.upload(c, samples, sizeof(uint32_t) * 4 * (size_t)f.n_pairs * batch));
+    if (sky) CHK(dsky.upload(c, sky, n));
+    if (omega) CHK(dom.upload(c, omega, sizeof(double) * 3 * batch));
+    if (omega && dt) CHK(ddt.upload(c, dt, sizeof(double) * batch));
+    CHK(dflow.alloc(n * 2 * sizeof(float)));
+    if (phi) CHK(dphi.alloc(n * sizeof(double)));
+    if (mask_fixed) CHK(dmf.alloc(n));
+    if (mask_dyn) CHK(dmd.alloc(n));
+    CHK(dres.alloc(sizeof(mav_result) * batch));
+    CHK(mav_process_batch_dev(c, dp.as<uint8_t>(), dn.as<uint8_t>(), ds.as<uint32_t>(), dom.as<double>(), ddt.as<double>(),
+                              dsky.as<uint8_t>(), batch, &f, tp, dflow.as<float>(), dphi.as<double>(), dmf.as<uint8_t>(),
+                              dmd.as<uint8_t>(), dres.as<mav_result>()));
+    if (flow) CHK(download(c, flow, dflow.p, n * 2 * sizeof(float)));
+    if (phi) CHK(download(c, phi, dphi.p, n * sizeof(double)));
+    if (mask_fixed) CHK(download(c, mask_fixed, dmf.p, n));
+    if (mask_dyn) CHK(download(c, mask_dyn, dmd.p, n));
+    CHK(download(c, results, dres.p, sizeof(mav_result) * batch));
+    return mav_sync(c);
+}
+
+// ---- stage hooks -------------------------------------------------------------------------------------------------
+static int layer_of(mav_ctx* c, int k, const Layer** l)
+{
+    if (!c) return fail(MAV_ERR_ARG, "NULL context");
+    if (k < 0 || k >= (int)c->layers.size()) return fail(MAV_ERR_ARG, "layer %d out of range", k);
+    HIPCHK(hipSetDevice(c->device));
+    *l = &c->layers[k];
+    return MAV_OK;
+}
+extern "C" int mav_stage_blur_resize(mav_ctx* c, const uint8_t* img, int k, float* out)
+{
+    const Layer* l;
+    CHK(layer_of(c, k, &l));
+    if (!img || !out) return fail(MAV_ERR_ARG, "mav_stage_blur_resize: NULL argument");
+    const size_t n = (size_t)l->w * l->h;
+    DevBuf di, dout;
+    CHK(di.upload(c, img, c->n0)); CHK(dout.alloc(n * sizeof(float)));
+    launch_blur_resize(c->stream, di.as<uint8_t>(), c->n0, 1, c->W, c->H, l->w, l->h, tables_of(*l), dout.as<float>(), n);
+    CHK(check_launch("blur_resize"));
+    CHK(download(c, out, dout.p, n * sizeof(float)));
+    return mav_sync(c);
+}
+extern "C" int mav_stage_polyexp(mav_ctx* c, const float* I, int k, float* R)
+{
+    const Layer* l;
+    CHK(layer_of(c, k, &l));
+    if (!I || !R) return fail(MAV_ERR_ARG, "mav_stage_polyexp: NULL argument");
+    const size_t n = (size_t)l->w * l->h;
+    DevBuf di, dr;
+    CHK(di.upload(c, I, n * sizeof(float))); CHK(dr.alloc(5 * n * sizeof(float)));
+    launch_polyexp(c->stream, di.as<float>(), n, 1, l->w, l->h, c->pc, dr.as<float>(), 5 * n);
+    CHK(check_launch("polyexp"));
+    CHK(download(c, R, dr.p, 5 * n * sizeof(float)));
+    return mav_sync(c);
+}
+extern "C" int mav_stage_update_matrices(mav_ctx* c, const float* R0, const float* R1, const float* flow, int k, float* M)
+{
+    const Layer* l;
+    CHK(layer_of(c, k, &l));
+    if (!R0 || !R1 || !flow || !M) return fail(MAV_ERR_ARG, "mav_stage_update_matrices: NULL argument");
+    const size_t n = (size_t)l->w * l->h;
+    DevBuf d0, d1, df, dm;
+    CHK(d0.upload(c, R0, 5 * n * sizeof(float))); CHK(d1.upload(c, R1, 5 * n * sizeof(float)));
+    CHK(df.upload(c, flow, 2 * n * sizeof(float))); CHK(dm.alloc(5 * n * sizeof(float)));
+    launch_update_matrices_flow(c->stream, d0.as<float>(), d1.as<float>(), 5 * n, df.as<float>(), 2 * n, 1, l->w, l->h, dm.as<float>(), 5 * n);
+    CHK(check_launch("update_matrices"));
+    CHK(download(c, M, dm.p, 5 * n * sizeof(float)));
+    return mav_sync(c);
+}
+extern "C" int mav_stage_blur_iter(mav_ctx* c, const float* R0, const float* R1, const float* M, int k, int update, float* flow, float* M_out)
+{
+    const Layer* l;
+    CHK(layer_of(c, k, &l));
+    if (!R0 || !R1 || !M || !flow || (update && !M_out)) return fail(MAV_ERR_ARG, "mav_stage_blur_iter: NULL argument");
+    const size_t n = (size_t)l->w * l->h;
+    DevBuf d0, d1, dm, dmo, df;
+    CHK(d0.upload(c, R0, 5 * n * sizeof(float))); CHK(d1.upload(c, R1, 5 * n * sizeof(float)));
+    CHK(dm.upload(c, M, 5 * n * sizeof(float))); CHK(dmo.alloc(5 * n * sizeof(float))); CHK(df.alloc(2 * n * sizeof(float)));
+    launch_blur_iter(c->stream, dm.as<float>(), dmo.as<float>(), 5 * n, d0.as<float>(), d1.as<float>(), 5 * n, 1, l->w, l->h,
+                     c->fb.winsize, update, df.as<float>(), 2 * n);
+    CHK(check_launch("blur_iter"));
+    CHK(download(c, flow, df.p, 2 * n * sizeof(float)));
+    if (update) CHK(download(c, M_out, dmo.p, 5 * n * sizeof(float)));
+    return mav_sync(c);
+}
+
+// ---- RCCL (loaded lazily so the single-GPU path carries no collective library) ----------------------------------------
+typedef int (*nccl_get_uid_t)(void*);
+struct uid128 { char b[128]; };  // ncclUniqueId is passed by value: 128 bytes
+typedef int (*nccl_init_rank2_t)(void**, int, uid128, int);
+typedef int (*nccl_destroy_t)(void*);
+typedef int (*nccl_allgather_t)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef const char* (*nccl_errstr_t)(int);
+static void* g_rccl = nullptr;
+static int rccl_sym(const char* name, void** fn)
+{
+    if (!g_rccl) {
+        g_rccl = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!g_rccl) g_rccl = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!g_rccl) return fail(MAV_ERR_STATE, "cannot load RCCL: %s", dlerror());
+    }
+    *fn = dlsym(g_rccl, name);
+    if (!*fn) return fail(MAV_ERR_STATE, "RCCL symbol %s missing", name);
+    return MAV_OK;
+}
+extern "C" int mav_comm_unique_id(void* id128)
+{
+    if (!id128) return fail(MAV_ERR_ARG, "mav_comm_unique_id: NULL");
+    void* fn;
+    CHK(rccl_sym("ncclGetUniqueId", &fn));
+    int rc = ((nccl_get_uid_t)fn)(id128);
+    return rc ? fail(MAV_ERR_HIP, "ncclGetUniqueId failed: %d", rc) : MAV_OK;
+}
+extern "C" int mav_comm_init(mav_ctx* c, const void* id128, int rank, int nranks, void** comm_out)
+{
+    if (!c || !id128 || !comm_out) return fail(MAV_ERR_ARG, "mav_comm_init: NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    void* fn;
+    CHK(rccl_sym("ncclCommInitRank", &fn));
+    uid128 id;
+    memcpy(&id, id128, sizeof(id));
+    int rc = ((nccl_init_rank2_t)fn)(comm_out, nranks, id, rank);
+    return rc ? fail(MAV_ERR_HIP, "ncclCommInitRank failed: %d", rc) : MAV_OK;
+}
+extern "C" int mav_comm_destroy(void* comm)
+{
+    if (!comm) return MAV_OK;
+    void* fn;
+    CHK(rccl_sym("ncclCommDestroy", &fn));
+    ((nccl_destroy_t)fn)(comm);
+    return MAV_OK;
+}
+extern "C" int mav_allgather_results(mav_ctx* c, void* comm, const void* local_dev, size_t bytes_per_rank, void* all_dev)
+{
+    if (!c || !comm || !local_dev || !all_dev) return fail(MAV_ERR_ARG, "mav_allgather_results: NULL argument");
+    void* fn;
+    CHK(rccl_sym("ncclAllGather", &fn));
+    int rc = ((nccl_allgather_t)fn)(local_dev, all_dev, bytes_per_rank, /* ncclInt8 */ 0, comm, c->stream);
+    return rc ? fail(MAV_ERR_HIP, "ncclAllGather failed: %d", rc) : MAV_OK;
+}

@@ -1,0 +1,75 @@
+// Internal declarations shared by the host side (mavflow.cpp) and the kernel translation units.
+// gfx950 only: wave = 64 lanes, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mavflow.h"
+
+#define MAV_MAX_POLY_N 16
+#define MAV_TILE 32  // flow-iteration tile edge (pixels)
+
+// FarnebackPrepareGaussian output, centre tap first (index k = |offset|).
+struct PolyCoef {
+    int n;
+    float g[MAV_MAX_POLY_N + 1], xg[MAV_MAX_POLY_N + 1], xxg[MAV_MAX_POLY_N + 1];
+    float ig11, ig03, ig33, ig55;
+};
+
+// Fused GaussianBlur + resize(INTER_LINEAR) as two 1-D tap tables: out(dx,dy) = sum_ty yw[dy][ty] * sum_tx xw[dx][tx] * src[yi[dy][ty]][xi[dx][tx]]
+struct ResizeTables {
+    int taps;          // ksize + 1
+    const int* xi;     // [w][taps]
+    const float* xw;   // [w][taps]
+    const int* yi;     // [h][taps]
+    const float* yw;   // [h][taps]
+};
+
+struct DerotParams {  // one pair; Detector.derotate
+    double o0, o1, o2, sx, sy;  // sx = w*dt/2, sy = h*dt/2
+    int enabled;
+};
+
+// ---- flow kernels (kernels_flow.hip) ----------------------------------------------------------------------
+// All take G slots; slot s reads/writes base + s*stride (strides in elements).
+void launch_blur_resize(hipStream_t st, const uint8_t* img, size_t img_stride, int G, int W, int H, int w, int h,
+                        ResizeTables t, float* out, size_t out_stride);
+void launch_polyexp(hipStream_t st, const float* I, size_t I_stride, int G, int w, int h, const PolyCoef& pc, float* R,
+                    size_t R_stride);
+// flow_prev == nullptr: zero initial flow. Otherwise flow = resize(prev (ph x pw x 2))*mul, evaluated inline.
+void launch_update_matrices(hipStream_t st, const float* R0, const float* R1, size_t R_stride, const float* flow_prev,
+                            size_t fp_stride, int pw, int ph, float mul, int G, int w, int h, float* M, size_t M_stride);
+// explicit per-pixel flow (h x w x 2), used by the stage hook
+void launch_update_matrices_flow(hipStream_t st, const float* R0, const float* R1, size_t R_stride, const float* flow,
+                                 size_t f_stride, int G, int w, int h, float* M, size_t M_stride);
+void launch_blur_iter(hipStream_t st, const float* M_in, float* M_out, size_t M_stride, const float* R0, const float* R1,
+                      size_t R_stride, int G, int w, int h, int winsize, int do_update, float* flow, size_t f_stride);
+size_t blur_iter_lds_bytes(int winsize);
+
+// ---- detection kernels (kernels_detect.hip, compiled with -ffp-contract=off) --------------------------------
+struct FoeScratch {
+    double* cand;                  // [B][N][2] compacted candidates
+    int* count;                    // [B]
+    unsigned long long* best_key;  // [B]
+};
+// FlowT = float (optionally derotated on the fly) or double (already derotated).
+void launch_foe_f32(hipStream_t st, const float* flow, const DerotParams* derot /*dev, [B] or null*/, const uint32_t* samples,
+                    int B, int W, int H, int N, double mag2_thr, double dist2_thr, FoeScratch s, double* foe);
+void launch_foe_f64(hipStream_t st, const double* flow, const uint32_t* samples, int B, int W, int H, int N, double mag2_thr,
+                    double dist2_thr, FoeScratch s, double* foe);
+// box_acc: [B][4] int32 accumulators (x0 min, y0 min, x1 max, y1 max), initialised by launch_box_init.
+void launch_box_init(hipStream_t st, int32_t* box_acc, unsigned long long* max_phi_bits, int B);
+void launch_phi_mask_f32(hipStream_t st, const float* flow, const DerotParams* derot, const double* foe, const uint8_t* sky,
+                         int B, int W, int H, mav_thr_params thr, double* phi, uint8_t* mask_fixed, uint8_t* mask_dyn,
+                         int32_t* box_acc, unsigned long long* max_phi_bits);
+void launch_phi_mask_f64(hipStream_t st, const double* flow, const double* foe, const uint8_t* sky, int B, int W, int H,
+                         mav_thr_params thr, double* phi, uint8_t* mask_fixed, uint8_t* mask_dyn, int32_t* box_acc,
+                         unsigned long long* max_phi_bits);
+void launch_finalize(hipStream_t st, const int32_t* box_acc, const double* foe, int B, mav_result* results);
+void launch_box_finalize(hipStream_t st, const int32_t* box_acc, int B, int32_t* box);
+void launch_derotate(hipStream_t st, const float* flow, const DerotParams* derot, int B, int W, int H, double* out);
+void launch_bbox_u8(hipStream_t st, const uint8_t* img, int B, int W, int H, int* maxv /*[B] scratch*/, int32_t* box_acc);
+void launch_window_max(hipStream_t st, const uint8_t* img, int B, int W, int H, unsigned long long* key /*[B]*/,
+                       int64_t* out);
+void launch_tpr_fpr(hipStream_t st, const uint8_t* gt, const uint8_t* mask, int B, int W, int H,
+                    unsigned long long* counts /*[B][4]*/);

@@ -1,0 +1,389 @@
+"""ctypes binding of libmavflow.so (include/mavflow.h).  No CPU fallback: if the library or a GPU is missing the
+product path raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(HERE, "libmavflow.so")
+
+MAV_OK, MAV_ERR_ARG, MAV_ERR_HIP, MAV_ERR_OOM, MAV_ERR_STATE = 0, -1, -2, -3, -4
+
+
+class MavflowError(RuntimeError):
+    """HIP / device failure inside libmavflow (the counterpart of cv2.error at the flow-operator seam)."""
+
+
+class FbParams(C.Structure):
+    _fields_ = [("pyr_scale", C.c_double), ("levels", C.c_int), ("winsize", C.c_int), ("iterations", C.c_int),
+                ("poly_n", C.c_int), ("poly_sigma", C.c_double), ("flags", C.c_int)]
+
+
+class FoeParams(C.Structure):
+    _fields_ = [("n_pairs", C.c_int), ("mag_threshold", C.c_double), ("ransac_threshold", C.c_double)]
+
+
+class ThrParams(C.Structure):
+    _fields_ = [("fixed_deg", C.c_double), ("fixed_min_mag", C.c_double), ("dyn_min_mag", C.c_double),
+                ("dyn_a", C.c_double), ("dyn_b", C.c_double), ("dyn_c", C.c_double)]
+
+
+class Result(C.Structure):
+    _fields_ = [("box", C.c_int32 * 4), ("foe", C.c_double * 2)]
+
+
+RESULT_DTYPE = np.dtype([("box", np.int32, (4,)), ("foe", np.float64, (2,))])
+assert RESULT_DTYPE.itemsize == C.sizeof(Result) == 32
+
+# every symbol include/mavflow.h declares (tests check the library exports each of them)
+EXPORTS = [
+    "mav_fb_defaults", "mav_foe_defaults", "mav_thr_defaults", "mav_create", "mav_destroy", "mav_last_error",
+    "mav_device_count", "mav_set_option", "mav_num_layers", "mav_layer_dims", "mav_farneback", "mav_derotate",
+    "mav_foe_dense", "mav_phi_mask", "mav_bbox", "mav_window_max", "mav_tpr_fpr_counts", "mav_process_batch",
+    "mav_farneback_dev", "mav_process_batch_dev", "mav_sync", "mav_stream", "mav_dev_alloc", "mav_dev_free",
+    "mav_memcpy_h2d", "mav_memcpy_d2h", "mav_timer_start", "mav_timer_stop", "mav_profile_enable", "mav_profile_get",
+    "mav_comm_unique_id", "mav_comm_init", "mav_comm_destroy", "mav_allgather_results", "mav_stage_blur_resize",
+    "mav_stage_polyexp", "mav_stage_update_matrices", "mav_stage_blur_iter",
+]
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libmavflow.so (built in-tree by `make -C mav-detection_amd/csrc` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise ImportError(f"{SO_PATH} is missing: build it with __graft_entry__.build(); there is no CPU fallback")
+    lib = C.CDLL(SO_PATH)
+    lib.mav_last_error.restype = C.c_char_p
+    lib.mav_stream.restype = C.c_void_p
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if name not in ("mav_last_error", "mav_stream", "mav_fb_defaults", "mav_foe_defaults", "mav_thr_defaults"):
+            fn.restype = C.c_int
+    lib.mav_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(FbParams)]
+    lib.mav_destroy.argtypes = [C.c_void_p]
+    lib.mav_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
+    lib.mav_num_layers.argtypes = [C.c_void_p]
+    lib.mav_layer_dims.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4
+    vp = C.c_void_p
+    lib.mav_farneback.argtypes = [vp, vp, vp, C.c_int, vp]
+    lib.mav_farneback_dev.argtypes = [vp, vp, vp, C.c_int, vp]
+    lib.mav_derotate.argtypes = [vp, vp, vp, vp, C.c_int, vp]
+    lib.mav_foe_dense.argtypes = [vp, vp, vp, C.c_int, C.POINTER(FoeParams), vp]
+    lib.mav_phi_mask.argtypes = [vp, vp, vp, vp, C.c_int, C.POINTER(ThrParams), vp, vp, vp, vp]
+    lib.mav_bbox.argtypes = [vp, vp, C.c_int, vp]
+    lib.mav_window_max.argtypes = [vp, vp, C.c_int, vp]
+    lib.mav_tpr_fpr_counts.argtypes = [vp, vp, vp, C.c_int, vp]
+    pb = [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.POINTER(FoeParams), C.POINTER(ThrParams), vp, vp, vp, vp, vp]
+    lib.mav_process_batch.argtypes = pb
+    lib.mav_process_batch_dev.argtypes = pb
+    lib.mav_sync.argtypes = [vp]
+    lib.mav_stream.argtypes = [vp]
+    lib.mav_dev_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    lib.mav_dev_free.argtypes = [vp, vp]
+    lib.mav_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.mav_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.mav_timer_start.argtypes = [vp]
+    lib.mav_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.mav_profile_enable.argtypes = [vp, C.c_int]
+    lib.mav_profile_get.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_long)]
+    lib.mav_comm_unique_id.argtypes = [vp]
+    lib.mav_comm_init.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.mav_comm_destroy.argtypes = [vp]
+    lib.mav_allgather_results.argtypes = [vp, vp, vp, C.c_size_t, vp]
+    lib.mav_stage_blur_resize.argtypes = [vp, vp, C.c_int, vp]
+    lib.mav_stage_polyexp.argtypes = [vp, vp, C.c_int, vp]
+    lib.mav_stage_update_matrices.argtypes = [vp, vp, vp, vp, C.c_int, vp]
+    lib.mav_stage_blur_iter.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp]
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    """Map an error code to the exception the reference raises at that seam."""
+    if rc == MAV_OK:
+        return
+    msg = load().mav_last_error().decode("utf-8", "replace")
+    if rc == MAV_ERR_ARG:
+        raise ValueError(msg)
+    if rc == MAV_ERR_OOM:
+        raise MemoryError(msg)
+    raise MavflowError(f"[{rc}] {msg}")
+
+
+def fb_defaults(levels: int | None = None) -> FbParams:
+    p = FbParams()
+    load().mav_fb_defaults(C.byref(p))
+    if levels is not None:
+        p.levels = levels
+    return p
+
+
+def foe_defaults() -> FoeParams:
+    p = FoeParams()
+    load().mav_foe_defaults(C.byref(p))
+    return p
+
+
+def thr_defaults() -> ThrParams:
+    p = ThrParams()
+    load().mav_thr_defaults(C.byref(p))
+    return p
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _arr(a, dtype, shape=None, name="array"):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=dtype)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(a.shape)}")
+    return a
+
+
+class DeviceBuffer:
+    """A hipMalloc'd buffer owned through the C-ABI (bench / multi-GPU path)."""
+
+    def __init__(self, ctx: "Context", nbytes: int):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        p = C.c_void_p()
+        check(ctx.lib.mav_dev_alloc(ctx.h, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, a: np.ndarray):
+        a = np.ascontiguousarray(a)
+        assert a.nbytes <= self.nbytes
+        check(self.ctx.lib.mav_memcpy_h2d(self.ctx.h, self.ptr, _ptr(a), a.nbytes))
+        return self
+
+    def download(self, dtype, shape) -> np.ndarray:
+        out = np.empty(shape, dtype)
+        assert out.nbytes <= self.nbytes
+        check(self.ctx.lib.mav_memcpy_d2h(self.ctx.h, _ptr(out), self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.mav_dev_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+
+class Context:
+    """One mav_ctx: (device, W, H, max_batch, Farneback parameters)."""
+
+    def __init__(self, W: int, H: int, max_batch: int = 1, fb: FbParams | None = None, device: int = 0):
+        self.lib = load()
+        self.W, self.H, self.max_batch = int(W), int(H), int(max_batch)
+        self.fb = fb if fb is not None else fb_defaults()
+        h = C.c_void_p()
+        check(self.lib.mav_create(C.byref(h), device, self.W, self.H, self.max_batch, C.byref(self.fb)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mav_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- introspection ---------------------------------------------------------------------------------------
+    def set_option(self, name: str, value: int):
+        check(self.lib.mav_set_option(self.h, name.encode(), int(value)))
+
+    def num_layers(self) -> int:
+        return self.lib.mav_num_layers(self.h)
+
+    def layer_dims(self, k: int):
+        w, h, ks, sg = C.c_int(), C.c_int(), C.c_int(), C.c_double()
+        check(self.lib.mav_layer_dims(self.h, k, C.addressof(w), C.addressof(h), C.addressof(ks), C.addressof(sg)))
+        return w.value, h.value, sg.value, ks.value
+
+    def sync(self):
+        check(self.lib.mav_sync(self.h))
+
+    def alloc(self, nbytes: int) -> DeviceBuffer:
+        return DeviceBuffer(self, nbytes)
+
+    # -- host-array entry points -----------------------------------------------------------------------------
+    def _imgs(self, a, name):
+        a = np.asarray(a)
+        if a.ndim == 2:
+            a = a[None]
+        if a.ndim != 3 or a.shape[1:] != (self.H, self.W):
+            raise ValueError(f"{name}: expected (batch, {self.H}, {self.W}) u8, got {a.shape}")
+        if a.dtype != np.uint8:
+            raise ValueError(f"{name}: expected uint8, got {a.dtype}")
+        return np.ascontiguousarray(a)
+
+    def farneback(self, prev, nxt) -> np.ndarray:
+        prev, nxt = self._imgs(prev, "prev"), self._imgs(nxt, "next")
+        if prev.shape != nxt.shape:
+            raise ValueError("prev and next differ in shape")
+        B = prev.shape[0]
+        flow = np.empty((B, self.H, self.W, 2), np.float32)
+        check(self.lib.mav_farneback(self.h, _ptr(prev), _ptr(nxt), B, _ptr(flow)))
+        return flow
+
+    def derotate(self, flow, omega, dt) -> np.ndarray:
+        flow = np.asarray(flow, np.float32)
+        flow = flow[None] if flow.ndim == 3 else flow
+        B = flow.shape[0]
+        flow = _arr(flow, np.float32, (B, self.H, self.W, 2), "flow")
+        omega = _arr(np.asarray(omega, np.float64).reshape(B, 3), np.float64)
+        dt = _arr(np.asarray(dt, np.float64).reshape(B), np.float64)
+        out = np.empty((B, self.H, self.W, 2), np.float64)
+        check(self.lib.mav_derotate(self.h, _ptr(flow), _ptr(omega), _ptr(dt), B, _ptr(out)))
+        return out
+
+    def foe_dense(self, flow, samples, params: FoeParams | None = None) -> np.ndarray:
+        flow = np.asarray(flow, np.float64)
+        flow = flow[None] if flow.ndim == 3 else flow
+        B = flow.shape[0]
+        p = params or foe_defaults()
+        flow = _arr(flow, np.float64, (B, self.H, self.W, 2), "flow")
+        samples = _arr(np.asarray(samples).reshape(B, 2 * p.n_pairs, 2), np.uint32)
+        foe = np.empty((B, 2), np.float64)
+        check(self.lib.mav_foe_dense(self.h, _ptr(flow), _ptr(samples), B, C.byref(p), _ptr(foe)))
+        return foe
+
+    def phi_mask(self, flow, foe, sky=None, params: ThrParams | None = None, want_phi=True):
+        flow = np.asarray(flow, np.float64)
+        flow = flow[None] if flow.ndim == 3 else flow
+        B = flow.shape[0]
+        flow = _arr(flow, np.float64, (B, self.H, self.W, 2), "flow")
+        foe = _arr(np.asarray(foe, np.float64).reshape(B, 2), np.float64)
+        sky = None if sky is None else _arr(np.asarray(sky).reshape(B, self.H, self.W).astype(np.uint8), np.uint8)
+        p = params or thr_defaults()
+        phi = np.empty((B, self.H, self.W), np.float64) if want_phi else None
+        mf = np.empty((B, self.H, self.W), np.uint8)
+        md = np.empty((B, self.H, self.W), np.uint8)
+        mx = np.empty(B, np.float64)
+        check(self.lib.mav_phi_mask(self.h, _ptr(flow), _ptr(foe), _ptr(sky), B, C.byref(p), _ptr(phi), _ptr(mf),
+                                    _ptr(md), _ptr(mx)))
+        return phi, mf.view(np.bool_), md.view(np.bool_), mx
+
+    def bbox(self, img) -> np.ndarray:
+        img = self._imgs(img, "img")
+        box = np.empty((img.shape[0], 4), np.int32)
+        check(self.lib.mav_bbox(self.h, _ptr(img), img.shape[0], _ptr(box)))
+        return box
+
+    def window_max(self, img) -> np.ndarray:
+        img = self._imgs(img, "img")
+        out = np.empty((img.shape[0], 3), np.int64)
+        check(self.lib.mav_window_max(self.h, _ptr(img), img.shape[0], _ptr(out)))
+        return out
+
+    def tpr_fpr_counts(self, gt, mask) -> np.ndarray:
+        gt = self._imgs(gt, "gt")
+        mask = self._imgs(np.asarray(mask).astype(np.uint8), "mask")
+        out = np.empty((gt.shape[0], 4), np.int64)
+        check(self.lib.mav_tpr_fpr_counts(self.h, _ptr(gt), _ptr(mask), gt.shape[0], _ptr(out)))
+        return out
+
+    def process_batch(self, prev, nxt, samples, omega=None, dt=None, sky=None, foe_params=None, thr_params=None,
+                      want_flow=True, want_phi=False, want_masks=True):
+        """Fused loop body of Processor.run_detection (processor.py:305-341) for a batch of pairs."""
+        prev, nxt = self._imgs(prev, "prev"), self._imgs(nxt, "next")
+        B = prev.shape[0]
+        fp = foe_params or foe_defaults()
+        tp = thr_params or thr_defaults()
+        samples = _arr(np.asarray(samples).reshape(B, 2 * fp.n_pairs, 2), np.uint32)
+        omega = None if omega is None else _arr(np.asarray(omega, np.float64).reshape(B, 3), np.float64)
+        dt = None if dt is None else _arr(np.asarray(dt, np.float64).reshape(B), np.float64)
+        sky = None if sky is None else _arr(np.asarray(sky).reshape(B, self.H, self.W).astype(np.uint8), np.uint8)
+        flow = np.empty((B, self.H, self.W, 2), np.float32) if want_flow else None
+        phi = np.empty((B, self.H, self.W), np.float64) if want_phi else None
+        mf = np.empty((B, self.H, self.W), np.uint8) if want_masks else None
+        md = np.empty((B, self.H, self.W), np.uint8) if want_masks else None
+        res = np.empty(B, RESULT_DTYPE)
+        check(self.lib.mav_process_batch(self.h, _ptr(prev), _ptr(nxt), _ptr(samples), _ptr(omega), _ptr(dt), _ptr(sky),
+                                         B, C.byref(fp), C.byref(tp), _ptr(flow), _ptr(phi), _ptr(mf), _ptr(md), _ptr(res)))
+        return dict(flow=flow, phi=phi, mask_fixed=None if mf is None else mf.view(np.bool_),
+                    mask_dyn=None if md is None else md.view(np.bool_), results=res)
+
+    # -- device-pointer path (bench, multi-GPU) --------------------------------------------------------------
+    def process_batch_dev(self, prev_ptr, next_ptr, samples_ptr, batch, results_ptr, flow_ptr=None, omega_ptr=None,
+                          dt_ptr=None, sky_ptr=None, phi_ptr=None, mf_ptr=None, md_ptr=None, foe_params=None,
+                          thr_params=None):
+        fp = foe_params or foe_defaults()
+        tp = thr_params or thr_defaults()
+        check(self.lib.mav_process_batch_dev(self.h, prev_ptr, next_ptr, samples_ptr, omega_ptr, dt_ptr, sky_ptr, batch,
+                                             C.byref(fp), C.byref(tp), flow_ptr, phi_ptr, mf_ptr, md_ptr, results_ptr))
+
+    def farneback_dev(self, prev_ptr, next_ptr, batch, flow_ptr):
+        check(self.lib.mav_farneback_dev(self.h, prev_ptr, next_ptr, batch, flow_ptr))
+
+    def timer_start(self):
+        check(self.lib.mav_timer_start(self.h))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        check(self.lib.mav_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    def profile_enable(self, on=True):
+        check(self.lib.mav_profile_enable(self.h, int(on)))
+
+    def profile_get(self) -> dict:
+        n = C.c_int(16)
+        names = (C.c_char_p * 16)()
+        ms = (C.c_double * 16)()
+        cnt = (C.c_long * 16)()
+        check(self.lib.mav_profile_get(self.h, C.byref(n), names, ms, cnt))
+        return {names[i].decode(): (ms[i], cnt[i]) for i in range(n.value)}
+
+    # -- stage hooks (parity tests) --------------------------------------------------------------------------
+    def stage_blur_resize(self, img, k):
+        img = _arr(img, np.uint8, (self.H, self.W), "img")
+        w, h, _, _ = self.layer_dims(k)
+        out = np.empty((h, w), np.float32)
+        check(self.lib.mav_stage_blur_resize(self.h, _ptr(img), k, _ptr(out)))
+        return out
+
+    def stage_polyexp(self, I, k):
+        w, h, _, _ = self.layer_dims(k)
+        I = _arr(I, np.float32, (h, w), "I")
+        R = np.empty((5, h, w), np.float32)
+        check(self.lib.mav_stage_polyexp(self.h, _ptr(I), k, _ptr(R)))
+        return R
+
+    def stage_update_matrices(self, R0, R1, flow, k):
+        w, h, _, _ = self.layer_dims(k)
+        R0 = _arr(R0, np.float32, (5, h, w), "R0"); R1 = _arr(R1, np.float32, (5, h, w), "R1")
+        flow = _arr(flow, np.float32, (h, w, 2), "flow")
+        M = np.empty((5, h, w), np.float32)
+        check(self.lib.mav_stage_update_matrices(self.h, _ptr(R0), _ptr(R1), _ptr(flow), k, _ptr(M)))
+        return M
+
+    def stage_blur_iter(self, R0, R1, M, k, update=True):
+        w, h, _, _ = self.layer_dims(k)
+        R0 = _arr(R0, np.float32, (5, h, w), "R0"); R1 = _arr(R1, np.float32, (5, h, w), "R1")
+        M = _arr(M, np.float32, (5, h, w), "M")
+        flow = np.empty((h, w, 2), np.float32)
+        Mo = np.empty((5, h, w), np.float32)
+        check(self.lib.mav_stage_blur_iter(self.h, _ptr(R0), _ptr(R1), _ptr(M), k, int(bool(update)), _ptr(flow), _ptr(Mo)))
+        return flow, (Mo if update else None)
+
+
+def device_count() -> int:
+    return load().mav_device_count()

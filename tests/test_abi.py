@@ -1,0 +1,71 @@
+"""CPU-side checks of the drop-in boundary: libmavflow.so loads, exports every symbol include/mavflow.h declares,
+has the struct layouts the header states, and refuses to run without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "mavflow.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mav_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(mav):
+    from mavflow import _lib
+    lib = _lib.load()
+    syms = header_symbols()
+    assert len(syms) >= 30
+    for s in syms:
+        assert hasattr(lib, s), f"libmavflow.so does not export {s}"
+    assert sorted(_lib.EXPORTS) == syms
+
+
+def test_struct_layouts(mav):
+    from mavflow import _lib
+    assert C.sizeof(_lib.Result) == 32 and _lib.RESULT_DTYPE.itemsize == 32
+    assert _lib.RESULT_DTYPE.fields["foe"][1] == 16
+    fb = _lib.fb_defaults()
+    assert (fb.pyr_scale, fb.levels, fb.winsize, fb.iterations, fb.poly_n, fb.poly_sigma, fb.flags) == (0.4, 1, 12, 10, 8, 1.2, 0)
+    fo = _lib.foe_defaults()
+    assert (fo.n_pairs, fo.mag_threshold, fo.ransac_threshold) == (1000, 2.5, 30.0)
+    th = _lib.thr_defaults()
+    assert (th.fixed_deg, th.fixed_min_mag, th.dyn_min_mag, th.dyn_a, th.dyn_b, th.dyn_c) == (15.0, 1.0, 0.5, 0.25, 0.5, 8.0)
+
+
+def test_no_cpu_fallback(mav):
+    """Without a GPU the product path must fail loudly, never compute on the host."""
+    from mavflow import _lib
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(_lib.MavflowError):
+        _lib.Context(64, 48, 1)
+
+
+def test_bad_arguments_are_value_errors(mav):
+    from mavflow import _lib
+    fb = _lib.fb_defaults()
+    fb.pyr_scale = 1.0                       # cv2 raises for pyr_scale >= 1
+    with pytest.raises(ValueError):
+        _lib.Context(64, 48, 1, fb)
+    fb = _lib.fb_defaults()
+    fb.flags = 256                           # OPTFLOW_FARNEBACK_GAUSSIAN: not implemented, says so
+    with pytest.raises(ValueError):
+        _lib.Context(64, 48, 1, fb)
+    with pytest.raises(ValueError):
+        _lib.Context(0, 48, 1)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "mav-detection_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                src = open(os.path.join(dp, f), errors="replace").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "farneback_oracle" not in src and "libfboracle" not in src, f

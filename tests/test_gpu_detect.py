@@ -1,0 +1,155 @@
+"""GPU parity for derotation, FoE fit, phi, threshold masks and boxes: libmavflow through the C-ABI against
+(1) fixtures the reference's own Python produced (tests/golden/foe_chain.npz) and (2) the numpy oracle on seeded
+inputs.  Bar: bit-exact for FoE, masks, boxes, counts and the derotated flow (all double arithmetic in the
+reference's order); phi itself to 4 ulp of 180 degrees because arccos comes from the device math library while
+numpy uses the host libm / SIMD routine (mask pixels whose phi sits within that band of a threshold are
+excluded from the bit-exact comparison and counted; none is expected)."""
+import numpy as np
+import pytest
+
+from oracle import foe_oracle as fo
+from mavflow import synth
+
+pytestmark = pytest.mark.gpu
+
+PHI_ATOL = 4 * np.spacing(180.0)      # 1.1e-13 degrees
+
+
+def beq(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and a.tobytes() == b.tobytes()
+
+
+def masks_equal(got, exp, phi, thr_values, mag):
+    """bit-exact, except pixels whose phi is within PHI_ATOL of the threshold that decided them"""
+    diff = got != exp
+    if not diff.any():
+        return 0
+    near = np.abs(phi - thr_values) <= PHI_ATOL
+    assert not (diff & ~near).any(), f"{int((diff & ~near).sum())} mask pixels differ away from the threshold"
+    return int(diff.sum())
+
+
+@pytest.fixture(scope="module")
+def ctx_small(mav):
+    from mavflow import _lib
+    with _lib.Context(160, 120, 4) as c:
+        yield c
+
+
+def test_golden_foe(ctx_small, golden):
+    flows = golden["foe_flow"]                                    # (4, 120, 160, 2) f64
+    samples = np.stack([golden[f"foe_samples_{c}"] for c in range(4)])
+    foe = ctx_small.foe_dense(flows, samples)
+    # cases 0 and 2 were float32 in the reference run: their magnitude gate ran in float32 (frame-0 quirk);
+    # promote-to-double agrees unless |flow2| sits within 1e-7 of 2.5, which these seeds do not hit
+    assert beq(foe, golden["foe_out"]), (foe, golden["foe_out"])
+
+
+def test_golden_foe_zero_and_empty(ctx_small, golden):
+    foe = ctx_small.foe_dense(np.zeros((1, 120, 160, 2)), golden["foe_samples_0"][None])
+    assert beq(foe[0], golden["foe_zero"]) and tuple(foe[0]) == (0.0, 0.0)
+
+
+def test_golden_phi_and_masks(ctx_small, golden):
+    flow = golden["foe_flow"][1]
+    foe = golden["foe_out"][1]
+    phi, mf, md, mx = ctx_small.phi_mask(flow, foe)
+    np.testing.assert_allclose(phi[0], golden["phi_out"][1], rtol=0, atol=PHI_ATOL)
+    assert abs(mx[0] - golden["phi_out"][1].max()) <= PHI_ATOL
+    assert np.array_equal(mf[0], golden["thr_nosky_fixed"])
+    assert np.array_equal(md[0], golden["thr_nosky_total"])
+    phi, mf, md, _ = ctx_small.phi_mask(flow, foe, sky=golden["thr_sky"])
+    assert np.array_equal(mf[0], golden["thr_sky_fixed"])
+    assert np.array_equal(md[0], golden["thr_sky_total"])
+
+
+def test_golden_phi_special_cases(ctx_small, golden):
+    fz = golden["phi_zero_flow_in"]
+    phi, _, _, _ = ctx_small.phi_mask(fz, (70.5, 40.25))
+    np.testing.assert_allclose(phi[0], golden["phi_zero_flow_out"], rtol=0, atol=PHI_ATOL)
+    assert np.all(phi[0][10:20, 10:20] == 90.0)                    # zero flow -> exactly 90 degrees
+    phi, _, _, _ = ctx_small.phi_mask(golden["foe_flow"][1], (80.0, 60.0))     # FoE on a pixel centre
+    np.testing.assert_allclose(phi[0], golden["phi_on_pixel_out"], rtol=0, atol=PHI_ATOL)
+    phi, mf, md, _ = ctx_small.phi_mask(fz, (float("nan"), 3.0))   # float('nan') FoE: no early-out, all zeros
+    assert beq(phi[0], golden["phi_float_nan_out"]) and not mf.any()
+
+
+def test_golden_bbox(ctx_small, golden):
+    def rect(b):
+        return [b[0], b[1], b[2] - b[0], b[3] - b[1]]
+    imgs = np.stack([golden["bbox_a_in"], np.zeros((120, 160), np.uint8), golden["bbox_gray_in"],
+                     golden["thr_nosky_fixed"].astype(np.uint8)])
+    box = ctx_small.bbox(imgs)
+    assert rect(box[0]) == list(golden["bbox_a"]) == [7, 5, 12, 3]
+    assert list(box[1]) == [-1, -1, -1, -1] and rect(box[1]) == list(golden["bbox_empty"])
+    assert rect(box[2]) == list(golden["bbox_gray"])
+    assert rect(box[3]) == list(golden["bbox_fixed"])
+
+
+def test_golden_derotate(ctx_small, golden):
+    dt = float(golden["derot_dt"])
+    out = ctx_small.derotate(golden["derot_in"], golden["derot_dangle"] / dt, dt)
+    assert beq(out[0], golden["derot_out"])
+
+
+def test_golden_tpr_fpr(ctx_small, golden):
+    cnt = ctx_small.tpr_fpr_counts(golden["tpr_gt"], golden["thr_nosky_fixed"])[0]
+    with np.errstate(all="ignore"):
+        got = np.array([cnt[2] / cnt[0], cnt[3] / cnt[1]])
+    assert beq(got, golden["tpr_out"])
+
+
+def test_window_max_level0(ctx_small):
+    rng = np.random.default_rng(8)
+    imgs = np.zeros((3, 120, 160), np.uint8)
+    imgs[0] = rng.integers(0, 256, (120, 160))
+    imgs[1, 30:50, 90:130] = 255
+    got = ctx_small.window_max(imgs)
+    for b in range(3):
+        assert tuple(got[b]) == fo.analyze_pyramid_level0(imgs[b]), b
+    assert tuple(got[2]) == (0, 0, 0)
+
+
+def test_chain_640x480_vs_golden_and_oracle(mav, golden):
+    """processor.py:305-341 order on a seeded 640x480 field: derotate -> FoE -> phi -> masks -> box."""
+    from mavflow import _lib
+    W, H = 640, 480
+    fl = synth.synthetic_flow(W, H, seed=3)
+    smp = synth.foe_samples(W, H, 0)
+    dt = float(golden["derot_dt"])
+    omega = golden["derot_dangle"] / dt
+    with _lib.Context(W, H, 1) as c:
+        der = c.derotate(fl, omega, dt)
+        foe = c.foe_dense(der, smp)
+        phi, mf, md, mx = c.phi_mask(der, foe)
+        box = c.bbox(mf.view(np.uint8))
+    assert beq(foe[0], golden["chain_foe"])
+    ref = fo.run_chain(fl, smp, omega, dt)
+    np.testing.assert_allclose(phi[0], ref["phi"], rtol=0, atol=PHI_ATOL)
+    assert np.array_equal(np.packbits(mf[0]), golden["chain_fixed_bits"])
+    assert np.array_equal(np.packbits(md[0]), golden["chain_total_bits"])
+    b = box[0]
+    assert [b[0], b[1], b[2] - b[0], b[3] - b[1]] == list(golden["chain_box"])
+    assert abs(mx[0] - float(golden["chain_max_flow"])) <= PHI_ATOL
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_foe_random_fields_vs_oracle(mav, seed):
+    """More RANSAC cases incl. ragged size and few candidates; bit-exact FoE."""
+    from mavflow import _lib
+    W, H = 333, 211
+    rng = np.random.default_rng(seed)
+    fl = synth.synthetic_flow(W, H, seed=seed, noise=0.5).astype(np.float64)
+    if seed == 2:
+        fl *= 0.12                                                 # most pairs fail the 2.5 px gate
+    smp = np.zeros((2000, 2), np.uint32)
+    smp[:, 0] = rng.integers(0, H, 2000)
+    smp[:, 1] = rng.integers(0, W, 2000)
+    with _lib.Context(W, H, 1) as c:
+        foe = c.foe_dense(fl, smp)
+        p = _lib.foe_defaults()
+        p.n_pairs = 100
+        foe100 = c.foe_dense(fl, smp[:200], p)
+    assert beq(foe[0], np.array(fo.get_foe_dense(fl, smp)))
+    assert beq(foe100[0], np.array(fo.get_foe_dense(fl, smp[:200])))
