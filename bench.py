@@ -102,9 +102,16 @@ def main():
         d_res = ctx.alloc(B * rec)
         res_ptr = d_res.ptr
 
+    d_mf = ctx.alloc(B * W * H)
+    d_md = ctx.alloc(B * W * H)
+
+    def run_batch():
+        # flow stays in the library's HBM workspace (flow_ptr=None); both threshold masks are written out (1 B/px each),
+        # the per-pair box + FoE records are the result
+        ctx.process_batch_dev(d_prev.ptr, d_next.ptr, d_smp.ptr, B, res_ptr, mf_ptr=d_mf.ptr, md_ptr=d_md.ptr)
+
     def step():
-        # flow stays in the library's HBM workspace (flow_ptr=None); masks are not requested: the box is the output
-        ctx.process_batch_dev(d_prev.ptr, d_next.ptr, d_smp.ptr, B, res_ptr)
+        run_batch()
         if dist is not None:
             ctx.sync()
             dist.all_gather_into_tensor(t_all, t_local)
@@ -135,7 +142,7 @@ def main():
     roofline = None
     if rank == 0 and not args.no_profile:
         ctx.profile_enable(True)
-        ctx.process_batch_dev(d_prev.ptr, d_next.ptr, d_smp.ptr, B, res_ptr)
+        run_batch()
         prof = ctx.profile_get()
         ctx.profile_enable(False)
         ms, launches = prof["blur_iter"]

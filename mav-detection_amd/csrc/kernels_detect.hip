@@ -11,6 +11,8 @@
 #include "mavflow_internal.h"
 
 #include <limits.h>
+#include <math.h>
+#include <stdlib.h>
 
 // Derotated flow vector at pixel (col, row) in double, reference operation order (detector.py:92-114).
 static __device__ __forceinline__ void flow_at(const float* __restrict__ flow, const DerotParams* __restrict__ dp, int W, int H,
@@ -205,6 +207,9 @@ void launch_box_init(hipStream_t st, int32_t* box_acc, unsigned long long* max_p
     hipLaunchKernelGGL(k_box_init, dim3((B + 63) / 64), dim3(64), 0, st, box_acc, max_phi_bits, B);
 }
 
+// Box extents of one wave -> the pair's accumulators.  The accumulators only ever grow, so a (possibly stale) read that
+// already contains this wave's extents makes the four same-address atomics unnecessary: after the first few waves of a
+// pair almost every wave skips them (they were the phi kernel's bottleneck: thousands of atomics on four words).
 static __device__ __forceinline__ void wave_box_commit(int x0, int y0, int x1, int y1, int32_t* acc)
 {
     for (int o = 32; o > 0; o >>= 1) {
@@ -212,16 +217,45 @@ static __device__ __forceinline__ void wave_box_commit(int x0, int y0, int x1, i
         x1 = max(x1, __shfl_xor(x1, o)); y1 = max(y1, __shfl_xor(y1, o));
     }
     if ((threadIdx.x & 63) == 0 && x1 >= 0) {
-        atomicMin(&acc[0], x0); atomicMin(&acc[1], y0); atomicMax(&acc[2], x1); atomicMax(&acc[3], y1);
+        const int c0 = __hip_atomic_load(&acc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int c1 = __hip_atomic_load(&acc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int c2 = __hip_atomic_load(&acc[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int c3 = __hip_atomic_load(&acc[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (x0 < c0) atomicMin(&acc[0], x0);
+        if (y0 < c1) atomicMin(&acc[1], y0);
+        if (x1 > c2) atomicMax(&acc[2], x1);
+        if (y1 > c3) atomicMax(&acc[3], y1);
     }
+}
+
+// Screening constants for the single-precision fast path (host-computed, see phi_screen()).
+struct PhiScreen {
+    int enabled;         // 0: every pixel takes the exact double path
+    float cos_fixed;     // cos(fixed_deg)
+    float fmm2, dmm2;    // fixed_min_mag^2, dyn_min_mag^2
+    float dyn_ab, dyn_c; // dyn_a + dyn_b, dyn_c
+};
+
+// Exact phi of one pixel (degrees), numpy order of operations (focus_of_expansion.py:163-177).
+static __device__ __forceinline__ double phi_exact(double u, double v, double d2x, double d2y, double* fm_out)
+{
+    const double fm = sqrt(u * u + v * v);
+    const double dist = sqrt(d2x * d2x + d2y * d2y);
+    const double prod = fm * dist;
+    const double norm = (prod > 1e-6 || prod != prod) ? prod : 1e-6;  // np.maximum propagates NaN
+    double arg = (u * d2x + v * d2y) / norm;
+    *fm_out = fm;
+    if (arg != arg) return 0.0;  // angle_diff[isnan] = 0
+    arg = arg < -1.0 ? -1.0 : (arg > 1.0 ? 1.0 : arg);
+    return acos(arg) * (180.0 / 3.141592653589793238462643383279502884);
 }
 
 template <typename FlowT>
 __global__ __launch_bounds__(256) void k_phi_mask(const FlowT* __restrict__ flow, const DerotParams* __restrict__ derot,
                                                   const double* __restrict__ foe, const uint8_t* __restrict__ sky, int W, int H,
-                                                  mav_thr_params thr, double* __restrict__ phi_out, uint8_t* __restrict__ mfix,
-                                                  uint8_t* __restrict__ mdyn, int32_t* __restrict__ box_acc,
-                                                  unsigned long long* __restrict__ max_phi_bits)
+                                                  mav_thr_params thr, PhiScreen scr, double* __restrict__ phi_out,
+                                                  uint8_t* __restrict__ mfix, uint8_t* __restrict__ mdyn,
+                                                  int32_t* __restrict__ box_acc, unsigned long long* __restrict__ max_phi_bits)
 {
     const int b = blockIdx.z;
     const int lane = threadIdx.x & 63;
@@ -240,31 +274,53 @@ __global__ __launch_bounds__(256) void k_phi_mask(const FlowT* __restrict__ flow
             double u, v;
             flow_at(fl, dp, W, H, y, x, &u, &v);
             const double d2x = (double)x - foex, d2y = (double)y - foey;
-            const double fm = sqrt(u * u + v * v);
-            const double dist = sqrt(d2x * d2x + d2y * d2y);
-            const double prod = fm * dist;
-            const double norm = (prod > 1e-6 || prod != prod) ? prod : 1e-6;  // np.maximum propagates NaN
-            double arg = (u * d2x + v * d2y) / norm;
-            double ph;
-            if (arg != arg) {
-                ph = 0.0;  // angle_diff[isnan] = 0
-            } else {
-                arg = arg < -1.0 ? -1.0 : (arg > 1.0 ? 1.0 : arg);
-                ph = acos(arg) * (180.0 / 3.141592653589793238462643383279502884);
-            }
             const size_t o = b * npx + (size_t)y * W + x;
             const bool notsky = sky ? (sky[o] == 0) : true;
-            const double t = thr.dyn_b + thr.dyn_c / fm;
-            const bool hi = ph > (thr.dyn_a + t);
-            const bool lo = ph < (thr.dyn_a - t);
-            const bool dyn = (fm > thr.dyn_min_mag) && notsky && (lo || hi);
-            const double gated = ((fm > thr.fixed_min_mag) && notsky) ? ph : 0.0;
-            const bool fix = gated > thr.fixed_deg;
-            if (phi_out) phi_out[o] = ph;
+            bool fix, dyn;
+            bool decided = false;
+            if (scr.enabled) {
+                // Single-precision screen.  phi > T  <=>  arg < cos(T)  (arccos is monotone), and every f32 quantity below
+                // is within 1e-6 (absolute, in arg units) / 1e-6 (relative, magnitudes) of its double counterpart, so a
+                // decision taken outside the guard bands is the decision the exact path would take.  Pixels inside a band
+                // (a ~1e-4 fraction) fall through to the exact path.
+                const float uf = (float)u, vf = (float)v, dxf = (float)d2x, dyf = (float)d2y;
+                const float m2 = uf * uf + vf * vf, dd = dxf * dxf + dyf * dyf;
+                const float prod2 = m2 * dd;
+                const float arg = (uf * dxf + vf * dyf) * rsqrtf(prod2);
+                bool sure = prod2 > 1e-8f && prod2 < 1e30f;       // norm floor (1e-6) and inf/NaN stay on the exact path
+                const bool gate_f = m2 > scr.fmm2, gate_d = m2 > scr.dmm2;
+                sure = sure && fabsf(m2 - scr.fmm2) > 1e-5f * scr.fmm2 && fabsf(m2 - scr.dmm2) > 1e-5f * scr.dmm2;
+                bool f = false, d = false;
+                if (gate_f && notsky) {
+                    sure = sure && fabsf(arg - scr.cos_fixed) > 2e-5f;
+                    f = arg < scr.cos_fixed;
+                }
+                if (gate_d && notsky) {
+                    const float T = scr.dyn_ab + scr.dyn_c * rsqrtf(m2);  // degrees
+                    if (T < 179.f) {
+                        const float cT = __cosf(T * 0.017453292519943295f);
+                        sure = sure && fabsf(arg - cT) > 1e-4f;
+                        d = arg < cT;
+                    } else
+                        sure = sure && T > 181.f;                         // phi <= 180 < T: certainly false
+                }
+                if (sure) { fix = f; dyn = d; decided = true; }
+            }
+            if (!decided) {
+                double fm;
+                const double ph = phi_exact(u, v, d2x, d2y, &fm);
+                const double t = thr.dyn_b + thr.dyn_c / fm;
+                const bool hi = ph > (thr.dyn_a + t);
+                const bool lo = ph < (thr.dyn_a - t);
+                dyn = (fm > thr.dyn_min_mag) && notsky && (lo || hi);
+                const double gated = ((fm > thr.fixed_min_mag) && notsky) ? ph : 0.0;
+                fix = gated > thr.fixed_deg;
+                if (phi_out) phi_out[o] = ph;
+                pmax = ph > pmax ? ph : pmax;
+            }
             if (mfix) mfix[o] = fix ? 1 : 0;
             if (mdyn) mdyn[o] = dyn ? 1 : 0;
             if (fix) { bx0 = min(bx0, x); bx1 = max(bx1, x); by0 = min(by0, y); by1 = max(by1, y); }
-            pmax = ph > pmax ? ph : pmax;
         }
     }
     wave_box_commit(bx0, by0, bx1, by1, box_acc + 4 * b);
@@ -274,8 +330,26 @@ __global__ __launch_bounds__(256) void k_phi_mask(const FlowT* __restrict__ flow
             const unsigned long long other = __shfl_xor(bits, o);
             bits = other > bits ? other : bits;
         }
-        if (lane == 0 && bits) atomicMax(&max_phi_bits[b], bits);
+        if (lane == 0 && bits > __hip_atomic_load(&max_phi_bits[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(&max_phi_bits[b], bits);
     }
+}
+
+// The screen is usable when neither phi nor max(phi) is requested and the thresholds are in the regime where
+// "lo" (phi < dyn_a - (dyn_b + dyn_c/mag)) can never fire and both angle thresholds lie in [0, 180).
+static PhiScreen phi_screen(const mav_thr_params& t, const double* phi, const unsigned long long* max_phi_bits)
+{
+    PhiScreen s{};
+    const bool ok = !phi && !max_phi_bits && t.fixed_deg >= 0.0 && t.fixed_deg < 179.0 && t.dyn_a - t.dyn_b <= 0.0 &&
+                    t.dyn_c >= 0.0 && t.dyn_a + t.dyn_b >= 0.0 && t.fixed_min_mag > 1e-3 && t.dyn_min_mag > 1e-3 &&
+                    t.fixed_min_mag < 1e6 && t.dyn_min_mag < 1e6 && t.dyn_c < 1e6 && t.dyn_a + t.dyn_b < 1e3;
+    { const char* e = getenv("MAVFLOW_NO_SCREEN"); s.enabled = ok && !(e && atoi(e) != 0); }
+    s.cos_fixed = (float)cos(t.fixed_deg * 3.141592653589793238462643383279502884 / 180.0);
+    s.fmm2 = (float)(t.fixed_min_mag * t.fixed_min_mag);
+    s.dmm2 = (float)(t.dyn_min_mag * t.dyn_min_mag);
+    s.dyn_ab = (float)(t.dyn_a + t.dyn_b);
+    s.dyn_c = (float)t.dyn_c;
+    return s;
 }
 
 void launch_phi_mask_f32(hipStream_t st, const float* flow, const DerotParams* derot, const double* foe, const uint8_t* sky,
@@ -283,16 +357,16 @@ void launch_phi_mask_f32(hipStream_t st, const float* flow, const DerotParams* d
                          int32_t* box_acc, unsigned long long* max_phi_bits)
 {
     dim3 grid((W + 255) / 256, (H + 3) / 4, B);
-    hipLaunchKernelGGL(k_phi_mask<float>, grid, dim3(256), 0, st, flow, derot, foe, sky, W, H, thr, phi, mask_fixed, mask_dyn,
-                       box_acc, max_phi_bits);
+    hipLaunchKernelGGL(k_phi_mask<float>, grid, dim3(256), 0, st, flow, derot, foe, sky, W, H, thr,
+                       phi_screen(thr, phi, max_phi_bits), phi, mask_fixed, mask_dyn, box_acc, max_phi_bits);
 }
 void launch_phi_mask_f64(hipStream_t st, const double* flow, const double* foe, const uint8_t* sky, int B, int W, int H,
                          mav_thr_params thr, double* phi, uint8_t* mask_fixed, uint8_t* mask_dyn, int32_t* box_acc,
                          unsigned long long* max_phi_bits)
 {
     dim3 grid((W + 255) / 256, (H + 3) / 4, B);
-    hipLaunchKernelGGL(k_phi_mask<double>, grid, dim3(256), 0, st, flow, (const DerotParams*)nullptr, foe, sky, W, H, thr, phi,
-                       mask_fixed, mask_dyn, box_acc, max_phi_bits);
+    hipLaunchKernelGGL(k_phi_mask<double>, grid, dim3(256), 0, st, flow, (const DerotParams*)nullptr, foe, sky, W, H, thr,
+                       phi_screen(thr, phi, max_phi_bits), phi, mask_fixed, mask_dyn, box_acc, max_phi_bits);
 }
 
 __global__ void k_finalize(const int32_t* __restrict__ box_acc, const double* __restrict__ foe, int B, mav_result* __restrict__ res,

@@ -15,6 +15,7 @@ static __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v <
 // Layer image: convertTo(f32) -> GaussianBlur(ksize, sigma, REFLECT_101) -> resize(INTER_LINEAR), fused through
 // the host-built 1-D tap tables (A.2).  One thread per output pixel; u8 source rows are re-read through L1/L2.
 // ------------------------------------------------------------------------------------------------------------
+template <int TAPS_T>   // > 0: tap tables of one output pixel live in registers; 0: runtime tap count
 __global__ __launch_bounds__(256) void k_blur_resize(const uint8_t* __restrict__ img, size_t img_stride, int W, int H,
                                                      int w, int h, ResizeTables t, float* __restrict__ out,
                                                      size_t out_stride)
@@ -22,28 +23,96 @@ __global__ __launch_bounds__(256) void k_blur_resize(const uint8_t* __restrict__
     const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
     const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (dx >= w || dy >= h) return;
+    const int taps = TAPS_T > 0 ? TAPS_T : t.taps;
     const uint8_t* src = img + (size_t)blockIdx.z * img_stride;
-    const int* xi = t.xi + (size_t)dx * t.taps;
-    const float* xw = t.xw + (size_t)dx * t.taps;
-    const int* yi = t.yi + (size_t)dy * t.taps;
-    const float* yw = t.yw + (size_t)dy * t.taps;
+    const int* xi = t.xi + (size_t)dx * taps;
+    const float* xw = t.xw + (size_t)dx * taps;
+    const int* yi = t.yi + (size_t)dy * taps;
+    const float* yw = t.yw + (size_t)dy * taps;
     float acc = 0.f;
-    for (int ty = 0; ty < t.taps; ty++) {
-        const float wy = yw[ty];
-        if (wy == 0.f) continue;
-        const uint8_t* row = src + (size_t)yi[ty] * W;
-        float r = 0.f;
-        for (int tx = 0; tx < t.taps; tx++) r += xw[tx] * (float)row[xi[tx]];
-        acc += wy * r;
+    if (TAPS_T > 0) {
+        int cx[TAPS_T > 0 ? TAPS_T : 1];
+        float cw[TAPS_T > 0 ? TAPS_T : 1];
+#pragma unroll
+        for (int tx = 0; tx < TAPS_T; tx++) { cx[tx] = xi[tx]; cw[tx] = xw[tx]; }
+#pragma unroll
+        for (int ty = 0; ty < TAPS_T; ty++) {
+            const float wy = yw[ty];
+            const uint8_t* row = src + (size_t)yi[ty] * W;
+            float r = 0.f;
+#pragma unroll
+            for (int tx = 0; tx < TAPS_T; tx++) r += cw[tx] * (float)row[cx[tx]];
+            acc += wy * r;
+        }
+    } else {
+        for (int ty = 0; ty < taps; ty++) {
+            const float wy = yw[ty];
+            if (wy == 0.f) continue;
+            const uint8_t* row = src + (size_t)yi[ty] * W;
+            float r = 0.f;
+            for (int tx = 0; tx < taps; tx++) r += xw[tx] * (float)row[xi[tx]];
+            acc += wy * r;
+        }
     }
     out[(size_t)blockIdx.z * out_stride + (size_t)dy * w + dx] = acc;
+}
+
+// Layer 0 (scale 1, sigma 0 -> fixed kernel [1/4, 1/2, 1/4], BORDER_REFLECT_101): every product is exact in f32,
+// so this is bit-identical to OpenCV's row-then-column filter.  One thread = 4 consecutive pixels x 4 rows:
+// six aligned u32 row loads + the two neighbour bytes per row, float4 stores.
+__global__ __launch_bounds__(256) void k_blur3_u8(const uint8_t* __restrict__ img, size_t img_stride, int W, int H,
+                                                  float* __restrict__ out, size_t out_stride)
+{
+    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 4;
+    if (x >= W || y0 >= H) return;
+    const uint8_t* src = img + (size_t)blockIdx.z * img_stride;
+    float* dst = out + (size_t)blockIdx.z * out_stride;
+    const int xl = x == 0 ? 1 : x - 1;                    // reflect101
+    const int xr = x + 4 >= W ? W - 2 : x + 4;
+    float hrow[6][4];
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        int yy = y0 - 1 + r;
+        yy = yy < 0 ? -yy : (yy >= H ? 2 * H - 2 - yy : yy);
+        yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);         // rows past the image (tail of the last group): any valid row
+        const uint8_t* p = src + (size_t)yy * W;
+        const uint32_t q = *(const uint32_t*)(p + x);
+        const float a = (float)p[xl], b0 = (float)(q & 255u), b1 = (float)((q >> 8) & 255u), b2 = (float)((q >> 16) & 255u),
+                    b3 = (float)(q >> 24), c = (float)p[xr];
+        hrow[r][0] = 0.5f * b0 + 0.25f * (a + b1);
+        hrow[r][1] = 0.5f * b1 + 0.25f * (b0 + b2);
+        hrow[r][2] = 0.5f * b2 + 0.25f * (b1 + b3);
+        hrow[r][3] = 0.5f * b3 + 0.25f * (b2 + c);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        if (y0 + r >= H) break;
+        float4 o;
+        o.x = 0.5f * hrow[r + 1][0] + 0.25f * (hrow[r][0] + hrow[r + 2][0]);
+        o.y = 0.5f * hrow[r + 1][1] + 0.25f * (hrow[r][1] + hrow[r + 2][1]);
+        o.z = 0.5f * hrow[r + 1][2] + 0.25f * (hrow[r][2] + hrow[r + 2][2]);
+        o.w = 0.5f * hrow[r + 1][3] + 0.25f * (hrow[r][3] + hrow[r + 2][3]);
+        *(float4*)(dst + (size_t)(y0 + r) * W + x) = o;
+    }
 }
 
 void launch_blur_resize(hipStream_t st, const uint8_t* img, size_t img_stride, int G, int W, int H, int w, int h,
                         ResizeTables t, float* out, size_t out_stride)
 {
+    if (w == W && h == H && t.taps == 4 && t.fixed3 && W % 4 == 0 && W >= 8 && H >= 2 && img_stride % 4 == 0 &&
+        out_stride % 4 == 0 && ((uintptr_t)img & 3) == 0 && ((uintptr_t)out & 15) == 0) {
+        dim3 grid((W / 4 + 63) / 64, ((H + 3) / 4 + 3) / 4, G);
+        hipLaunchKernelGGL(k_blur3_u8, grid, dim3(256), 0, st, img, img_stride, W, H, out, out_stride);
+        return;
+    }
     dim3 grid((w + 63) / 64, (h + 3) / 4, G);
-    hipLaunchKernelGGL(k_blur_resize, grid, dim3(256), 0, st, img, img_stride, W, H, w, h, t, out, out_stride);
+    if (t.taps == 6)
+        hipLaunchKernelGGL(k_blur_resize<6>, grid, dim3(256), 0, st, img, img_stride, W, H, w, h, t, out, out_stride);
+    else if (t.taps == 4)
+        hipLaunchKernelGGL(k_blur_resize<4>, grid, dim3(256), 0, st, img, img_stride, W, H, w, h, t, out, out_stride);
+    else
+        hipLaunchKernelGGL(k_blur_resize<0>, grid, dim3(256), 0, st, img, img_stride, W, H, w, h, t, out, out_stride);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -137,19 +206,14 @@ void launch_polyexp(hipStream_t st, const float* I, size_t I_stride, int G, int 
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// FarnebackUpdateMatrices for one pixel (A.5): bilinear gather of the 5 R1 planes at (x+u, y+v), border damping,
-// the five products.  R0p/R1p point at plane 0 of the pair; planes are npx apart.
-// ------------------------------------------------------------------------------------------------------------
-static __device__ __forceinline__ void update_px(const float* __restrict__ R0p, const float* __restrict__ R1p, size_t npx,
-                                                 int w, int h, int x, int y, float dx, float dy, float* __restrict__ Mp)
+// FarnebackUpdateMatrices for one pixel (A.5), register form: q[] = the 5 R0 values at (x, y), out[] = the 5 M values.
+static __device__ __forceinline__ void update_core(const float q[5], const float* __restrict__ R1p, size_t npx, int w, int h,
+                                                   int x, int y, float dx, float dy, float out[5])
 {
-    const size_t idx = (size_t)y * w + x;
     float fx = x + dx, fy = y + dy;
     const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
     fx -= x1; fy -= y1;
     float r2, r3, r4, r5, r6;
-    const float q0 = R0p[idx], q1 = R0p[npx + idx], q2 = R0p[2 * npx + idx], q3 = R0p[3 * npx + idx],
-                q4 = R0p[4 * npx + idx];
     if ((unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1)) {
         const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
         const float* p = R1p + (size_t)y1 * w + x1;
@@ -158,15 +222,15 @@ static __device__ __forceinline__ void update_px(const float* __restrict__ R0p, 
         r4 = a00 * p[0] + a01 * p[1] + a10 * p[w] + a11 * p[w + 1]; p += npx;
         r5 = a00 * p[0] + a01 * p[1] + a10 * p[w] + a11 * p[w + 1]; p += npx;
         r6 = a00 * p[0] + a01 * p[1] + a10 * p[w] + a11 * p[w + 1];
-        r4 = (q2 + r4) * 0.5f;
-        r5 = (q3 + r5) * 0.5f;
-        r6 = (q4 + r6) * 0.25f;
+        r4 = (q[2] + r4) * 0.5f;
+        r5 = (q[3] + r5) * 0.5f;
+        r6 = (q[4] + r6) * 0.25f;
     } else {
         r2 = r3 = 0.f;
-        r4 = q2; r5 = q3; r6 = q4 * 0.5f;
+        r4 = q[2]; r5 = q[3]; r6 = q[4] * 0.5f;
     }
-    r2 = (q0 - r2) * 0.5f;
-    r3 = (q1 - r3) * 0.5f;
+    r2 = (q[0] - r2) * 0.5f;
+    r3 = (q[1] - r3) * 0.5f;
     r2 += r4 * dy + r6 * dx;
     r3 += r6 * dy + r5 * dx;
     const int BORDER = 5;
@@ -177,11 +241,37 @@ static __device__ __forceinline__ void update_px(const float* __restrict__ R0p, 
                             (y < BORDER ? bw(y) : 1.f) * (y >= h - BORDER ? bw(h - y - 1) : 1.f);
         r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
     }
-    Mp[idx] = r4 * r4 + r6 * r6;
-    Mp[npx + idx] = (r4 + r5) * r6;
-    Mp[2 * npx + idx] = r5 * r5 + r6 * r6;
-    Mp[3 * npx + idx] = r4 * r2 + r6 * r3;
-    Mp[4 * npx + idx] = r6 * r2 + r5 * r3;
+    out[0] = r4 * r4 + r6 * r6;
+    out[1] = (r4 + r5) * r6;
+    out[2] = r5 * r5 + r6 * r6;
+    out[3] = r4 * r2 + r6 * r3;
+    out[4] = r6 * r2 + r5 * r3;
+}
+
+// memory form: R0p/R1p/Mp point at plane 0 of the pair; planes are npx apart.
+static __device__ __forceinline__ void update_px(const float* __restrict__ R0p, const float* __restrict__ R1p, size_t npx,
+                                                 int w, int h, int x, int y, float dx, float dy, float* __restrict__ Mp)
+{
+    const size_t idx = (size_t)y * w + x;
+    float q[5], o[5];
+#pragma unroll
+    for (int c = 0; c < 5; c++) q[c] = R0p[c * npx + idx];
+    update_core(q, R1p, npx, w, h, x, y, dx, dy, o);
+#pragma unroll
+    for (int c = 0; c < 5; c++) Mp[c * npx + idx] = o[c];
+}
+
+// 2x2 solve of the blurred system (A.6).  Differences of products with one fused rounding each (Kahan): the CPU path
+// does this step in double.
+static __device__ __forceinline__ void solve_px(float g11, float g12, float g22, float h1, float h2, float* u, float* v)
+{
+    const float p = g12 * g12, pe = fmaf(g12, g12, -p);
+    const float det = (fmaf(g11, g22, -p) - pe) + 1e-3f;
+    const float idet = 1.f / det;
+    const float qa = g12 * h1, qae = fmaf(g12, h1, -qa);
+    const float qb = g12 * h2, qbe = fmaf(g12, h2, -qb);
+    *u = (fmaf(g11, h2, -qa) - qae) * idet;
+    *v = (fmaf(g22, h1, -qb) - qbe) * idet;
 }
 
 // Initial M of a layer.  flow = 0 (top layer), resize(prevFlow)*mul evaluated inline (lower layers), or an
@@ -272,7 +362,7 @@ size_t blur_iter_lds_bytes(int winsize)
 }
 
 template <int M_T>
-__global__ __launch_bounds__(256) void k_blur_iter(const float* __restrict__ M_in, float* __restrict__ M_out, size_t M_stride,
+__global__ __launch_bounds__(256) void k_blur_iter_generic(const float* __restrict__ M_in, float* __restrict__ M_out, size_t M_stride,
                                                    const float* __restrict__ R0, const float* __restrict__ R1, size_t R_stride,
                                                    int w, int h, int m_rt, int pitch, int plane, float scale, int do_update,
                                                    float* __restrict__ flow, size_t f_stride)
@@ -339,32 +429,194 @@ __global__ __launch_bounds__(256) void k_blur_iter(const float* __restrict__ M_i
         const float* L = lds + ly * pitch + lx;
         const float g11 = L[0] * scale, g12 = L[plane] * scale, g22 = L[2 * plane] * scale, h1 = L[3 * plane] * scale,
                     h2 = L[4 * plane] * scale;
-        // differences of products with one fused rounding each (Kahan): the CPU path does this step in double
-        const float p = g12 * g12, pe = fmaf(g12, g12, -p);
-        const float det = (fmaf(g11, g22, -p) - pe) + 1e-3f;
-        const float idet = 1.f / det;
-        const float qa = g12 * h1, qae = fmaf(g12, h1, -qa);
-        const float qb = g12 * h2, qbe = fmaf(g12, h2, -qb);
-        const float u = (fmaf(g11, h2, -qa) - qae) * idet;
-        const float v = (fmaf(g22, h1, -qb) - qbe) * idet;
+        float u, v;
+        solve_px(g11, g12, g22, h1, h2, &u, &v);
         *(float2*)(fo + ((size_t)gy * w + gx) * 2) = make_float2(u, v);
         if (do_update) update_px(R0p, R1p, npx, w, h, gx, gy, u, v, Mo);
     }
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// Fast form of the sweep for a compile-time half-window M_T (winsize 12 -> 6), image width a multiple of 4.
+// Tile = 64 x 16 pixels per 256-thread workgroup; tiles are numbered so that the workgroups one XCD receives
+// (blockIdx % 8, round-robin dispatch) walk one contiguous band of the image: halo rows are re-read from that XCD's L2.
+//   phase A  one thread per (plane, tile column): the 16+2m rows of its column come straight from HBM/L2 into
+//            registers (lanes = consecutive columns: coalesced row segments, all loads independent); the vertical
+//            sliding sums are formed in registers and only those 16 sums are written to LDS
+//   barrier
+//   phase B  one thread per 4 consecutive pixels of a row.  Lanes are assigned by the hardware's ds_read_b128 lane
+//            groups ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32): each group reads 16 consecutive float4 of ONE row =
+//            all 64 banks once, so the 4 reads per plane are conflict-free at any pitch.  Horizontal sliding sums in
+//            registers, 2x2 solve, flow -> HBM (float4 x2) and -> LDS
+//   barrier
+//   phase C  UpdateMatrices with lane = pixel column (64 consecutive pixels per wave): R0 loads, the 20 R1 gather
+//            loads and the 5 M' stores are all row-contiguous across the wave
+// LDS: 5 x 16 x 76 floats of vertical sums + 16 x 64 float2 of flow = 32.5 KB -> 4 workgroups per CU.  Raw M never
+// touches LDS.
+// ------------------------------------------------------------------------------------------------------------
+#define FT_X 64
+#define FT_Y 16
+template <int M_T>
+__global__ __launch_bounds__(256) void k_blur_iter_fast(const float* __restrict__ M_in, float* __restrict__ M_out,
+                                                        size_t M_stride, const float* __restrict__ R0,
+                                                        const float* __restrict__ R1, size_t R_stride, int w, int h,
+                                                        int tiles_x, int tiles_per_img, int n_tiles, float scale,
+                                                        int do_update, float* __restrict__ flow, size_t f_stride)
+{
+    constexpr int EXT_X = FT_X + 2 * M_T;              // 76
+    constexpr int EXT_Y = FT_Y + 2 * M_T;              // 28
+    constexpr int WIN = 2 * M_T + 1;                   // 13
+    constexpr int PITCH = (EXT_X + 3) & ~3;            // 76
+    constexpr int PLANE = FT_Y * PITCH + (EXT_X - (FT_Y * PITCH) % 32 + 64) % 32;   // = EXT_X (mod 32): phase-A lanes stay on distinct banks across planes
+    static_assert(PLANE % 4 == 0, "plane must keep 16-byte alignment");
+    __shared__ __attribute__((aligned(16))) float vs[5 * PLANE];
+    __shared__ __attribute__((aligned(16))) float2 fl[FT_Y * FT_X];
+    const int tid = threadIdx.x;
+    // XCD-aware tile order: workgroups b, b+8, b+16, ... (one XCD) take consecutive tiles of one band
+    const int nb = gridDim.x;
+    const int per = (nb + 7) >> 3;
+    const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (tile >= n_tiles) return;
+    const int s = tile / tiles_per_img;
+    const int tr = tile - s * tiles_per_img;
+    const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+    const int x0 = tx * FT_X, y0 = ty * FT_Y;
+    const size_t npx = (size_t)w * h;
+    const float* Min = M_in + (size_t)s * M_stride;
+
+    for (int t = tid; t < 5 * EXT_X; t += 256) {
+        const int c = t / EXT_X, lx = t - c * EXT_X;
+        const int gx = clampi(x0 - M_T + lx, 0, w - 1);
+        const float* col = Min + c * npx + gx;
+        float v[EXT_Y];
+#pragma unroll
+        for (int i = 0; i < EXT_Y; i++) v[i] = col[(size_t)clampi(y0 - M_T + i, 0, h - 1) * w];
+        float* out = vs + c * PLANE + lx;
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < WIN; i++) sum += v[i];
+        out[0] = sum;
+#pragma unroll
+        for (int y = 1; y < FT_Y; y++) {
+            sum += v[y + WIN - 1] - v[y - 1];
+            out[y * PITCH] = sum;
+        }
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, wv = tid >> 6;
+    {
+        // hardware b128 lane group and position inside it
+        const int l5 = lane & 31;
+        const int grp = (lane >> 5) * 2 + (((l5 >> 2) == 1 || (l5 >> 2) == 2 || (l5 >> 2) == 4 || (l5 >> 2) == 7) ? 1 : 0);
+        // groups (quads of 4 lanes): g0 = quads {0,3,5,6}, g1 = quads {1,2,4,7}
+        const int quad = l5 >> 2;
+        const int qpos = (quad == 0 || quad == 1) ? 0 : ((quad == 3 || quad == 2) ? 1 : ((quad == 5 || quad == 4) ? 2 : 3));
+        const int pos = qpos * 4 + (lane & 3);          // 0..15 inside the group
+        const int ly = wv * 4 + grp;                     // tile row 0..15
+        const int lx0 = pos * 4;
+        const int gx = x0 + lx0, gy = y0 + ly;
+        float S[5][4];
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            const float4* p = (const float4*)(vs + c * PLANE + ly * PITCH + lx0);
+            constexpr int NV = (4 + 2 * M_T + 3) / 4;
+            float f[4 * NV];
+#pragma unroll
+            for (int k = 0; k < NV; k++) {
+                const float4 q = p[k];
+                f[4 * k] = q.x; f[4 * k + 1] = q.y; f[4 * k + 2] = q.z; f[4 * k + 3] = q.w;
+            }
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < WIN; k++) a += f[k];
+            S[c][0] = a;
+#pragma unroll
+            for (int j = 1; j < 4; j++) {
+                a += f[j + WIN - 1] - f[j - 1];
+                S[c][j] = a;
+            }
+        }
+        float u[4], v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            solve_px(S[0][j] * scale, S[1][j] * scale, S[2][j] * scale, S[3][j] * scale, S[4][j] * scale, &u[j], &v[j]);
+        if (gx < w && gy < h) {                          // w % 4 == 0: the 4 pixels are all inside or all outside
+            float* fo = flow + (size_t)s * f_stride + ((size_t)gy * w + gx) * 2;
+            *(float4*)fo = make_float4(u[0], v[0], u[1], v[1]);
+            *(float4*)(fo + 4) = make_float4(u[2], v[2], u[3], v[3]);
+        }
+        if (do_update) {
+            float4* fp = (float4*)(fl + ly * FT_X + lx0);
+            fp[0] = make_float4(u[0], v[0], u[1], v[1]);
+            fp[1] = make_float4(u[2], v[2], u[3], v[3]);
+        }
+    }
+    if (!do_update) return;
+    __syncthreads();
+
+    const float* R0p = R0 + (size_t)s * R_stride;
+    const float* R1p = R1 + (size_t)s * R_stride;
+    float* Mo = M_out + (size_t)s * M_stride;
+    const int gx = x0 + lane;
+    if (gx >= w) return;
+    // all four pixels' loads are issued before any of their arithmetic: rows past the image are clamped for the
+    // loads and only their stores are skipped
+    float q[4][5], fu[4], fv[4];
+    int gys[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int ly = wv * 4 + j;
+        gys[j] = min(y0 + ly, h - 1);
+        const float2 f = fl[ly * FT_X + lane];
+        fu[j] = f.x; fv[j] = f.y;
+        const size_t idx = (size_t)gys[j] * w + gx;
+#pragma unroll
+        for (int c = 0; c < 5; c++) q[j][c] = R0p[c * npx + idx];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        float o[5];
+        update_core(q[j], R1p, npx, w, h, gx, gys[j], fu[j], fv[j], o);
+        if (y0 + wv * 4 + j < h) {
+            const size_t idx = (size_t)gys[j] * w + gx;
+#pragma unroll
+            for (int c = 0; c < 5; c++) Mo[c * npx + idx] = o[c];
+        }
+    }
+}
+
+static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 void launch_blur_iter(hipStream_t st, const float* M_in, float* M_out, size_t M_stride, const float* R0, const float* R1,
                       size_t R_stride, int G, int w, int h, int winsize, int do_update, float* flow, size_t f_stride)
 {
     int ext, pitch, plane;
     const int m = winsize / 2;
-    iter_geometry(m, &ext, &pitch, &plane);
-    const size_t lds = sizeof(float) * 5 * (size_t)plane;
     const float scale = (float)(1.0 / ((double)winsize * winsize));
     dim3 grid((w + MAV_TILE - 1) / MAV_TILE, (h + MAV_TILE - 1) / MAV_TILE, G);
+    const bool vec_ok = (w % 4 == 0) && (M_stride % 4 == 0) && (R_stride % 4 == 0) && (f_stride % 4 == 0) && aligned16(M_in) &&
+                        aligned16(M_out) && aligned16(R0) && aligned16(R1) && aligned16(flow);
+    if (m == 6 && vec_ok) {
+        const int tiles_x = (w + FT_X - 1) / FT_X, tiles_y = (h + FT_Y - 1) / FT_Y;
+        const int per_img = tiles_x * tiles_y, n_tiles = per_img * G;
+        const int nb = ((n_tiles + 7) / 8) * 8;        // the XCD-aware renumbering needs a multiple of 8 workgroups
+        hipLaunchKernelGGL(k_blur_iter_fast<6>, dim3(nb), dim3(256), 0, st, M_in, M_out, M_stride, R0, R1, R_stride, w, h,
+                           tiles_x, per_img, n_tiles, scale, do_update, flow, f_stride);
+        return;
+    }
+    iter_geometry(m, &ext, &pitch, &plane);
+    const size_t lds = sizeof(float) * 5 * (size_t)plane;
     if (m == 6)
-        hipLaunchKernelGGL(k_blur_iter<6>, grid, dim3(256), lds, st, M_in, M_out, M_stride, R0, R1, R_stride, w, h, m, pitch,
-                           plane, scale, do_update, flow, f_stride);
-    else
-        hipLaunchKernelGGL(k_blur_iter<0>, grid, dim3(256), lds, st, M_in, M_out, M_stride, R0, R1, R_stride, w, h, m, pitch,
-                           plane, scale, do_update, flow, f_stride);
+        hipLaunchKernelGGL(k_blur_iter_generic<6>, grid, dim3(256), lds, st, M_in, M_out, M_stride, R0, R1, R_stride, w, h, m,
+                           pitch, plane, scale, do_update, flow, f_stride);
+    else {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)k_blur_iter_generic<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_blur_iter_generic<0>, grid, dim3(256), lds, st, M_in, M_out, M_stride, R0, R1, R_stride, w, h, m,
+                           pitch, plane, scale, do_update, flow, f_stride);
+    }
 }

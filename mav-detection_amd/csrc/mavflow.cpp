@@ -474,7 +474,7 @@ static int check_launch(const char* what)
 }
 
 // ---- Farneback pipeline ----------------------------------------------------------------------------------
-static ResizeTables tables_of(const Layer& l) { return ResizeTables{l.ksize + 1, l.xi, l.xw, l.yi, l.yw}; }
+static ResizeTables tables_of(const Layer& l) { return ResizeTables{l.ksize + 1, (l.ksize == 3 && l.sigma <= 0) ? 1 : 0, l.xi, l.xw, l.yi, l.yw}; }
 
 static int farneback_group(mav_ctx* c, const uint8_t* prev, const uint8_t* next, int g, float* flow_out)
 {

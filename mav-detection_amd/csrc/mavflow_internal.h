@@ -19,6 +19,7 @@ struct PolyCoef {
 // Fused GaussianBlur + resize(INTER_LINEAR) as two 1-D tap tables: out(dx,dy) = sum_ty yw[dy][ty] * sum_tx xw[dx][tx] * src[yi[dy][ty]][xi[dx][tx]]
 struct ResizeTables {
     int taps;          // ksize + 1
+    int fixed3;        // ksize == 3 with the fixed kernel [1/4, 1/2, 1/4] (sigma == 0) and no resampling
     const int* xi;     // [w][taps]
     const float* xw;   // [w][taps]
     const int* yi;     // [h][taps]

@@ -276,7 +276,7 @@ class Context:
         phi = np.empty((B, self.H, self.W), np.float64) if want_phi else None
         mf = np.empty((B, self.H, self.W), np.uint8)
         md = np.empty((B, self.H, self.W), np.uint8)
-        mx = np.empty(B, np.float64)
+        mx = np.empty(B, np.float64) if want_phi else None      # max(phi) needs the exact path, like phi itself
         check(self.lib.mav_phi_mask(self.h, _ptr(flow), _ptr(foe), _ptr(sky), B, C.byref(p), _ptr(phi), _ptr(mf),
                                     _ptr(md), _ptr(mx)))
         return phi, mf.view(np.bool_), md.view(np.bool_), mx

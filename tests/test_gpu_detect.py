@@ -153,3 +153,57 @@ def test_foe_random_fields_vs_oracle(mav, seed):
         foe100 = c.foe_dense(fl, smp[:200], p)
     assert beq(foe[0], np.array(fo.get_foe_dense(fl, smp)))
     assert beq(foe100[0], np.array(fo.get_foe_dense(fl, smp[:200])))
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_screened_masks_equal_exact_masks(mav, golden, seed):
+    """When neither phi nor max(phi) is requested the kernel screens pixels in single precision and only runs the
+    double path inside the guard bands: the masks and the box must not change by a single pixel."""
+    from mavflow import _lib
+    W, H = 640, 480
+    fl = synth.synthetic_flow(W, H, seed=10 + seed, noise=0.3).astype(np.float64)
+    fl[100:140, 200:260] *= 0.01                        # a patch under both magnitude gates
+    fl[300:310, 50:60] = 0.0                            # zero flow: norm floor -> exact path
+    fl[5, 5] = np.nan
+    fl[6, 6] = np.inf
+    sky = np.zeros((H, W), bool)
+    sky[:40] = True
+    foe = (0.55 * W + 0.3, 0.45 * H - 0.2)
+    with _lib.Context(W, H, 1) as c:
+        phi, mf, md, _ = c.phi_mask(fl, foe, sky=sky)
+        _, mf2, md2, _ = c.phi_mask(fl, foe, sky=sky, want_phi=False)
+        th = _lib.thr_defaults()
+        th.fixed_deg, th.dyn_c = 3.0, 2.0               # other thresholds, still inside the screen's regime
+        _, mf3, md3, _ = c.phi_mask(fl, foe, params=th)
+        _, mf4, md4, _ = c.phi_mask(fl, foe, params=th, want_phi=False)
+    assert np.array_equal(mf, mf2) and np.array_equal(md, md2)
+    assert np.array_equal(mf3, mf4) and np.array_equal(md3, md4)
+    assert mf.sum() > 100 and md.sum() > 100 and mf3.sum() > mf.sum()
+    with np.errstate(all="ignore"):
+        rf, rd = fo.threshold_masks(fo.get_phi(fl, foe), fo.get_magnitude(fl), sky)
+    assert np.array_equal(mf2[0], rf) and np.array_equal(md2[0], rd)
+
+
+def test_process_batch_equals_staged_calls(mav):
+    """The fused entry point (frames in, records out) must agree with the staged calls on its own flow."""
+    from mavflow import _lib
+    W, H, B = 320, 240, 3
+    prev, nxt = synth.make_batch(W, H, B, distinct=3)
+    smp = np.stack([synth.foe_samples(W, H, b) for b in range(B)])
+    omega = np.array([[0.2, -0.1, 0.05]] * B)
+    dt = np.full(B, 1 / 30.0)
+    sky = np.zeros((B, H, W), bool)
+    sky[:, :20] = True
+    with _lib.Context(W, H, B) as c:
+        out = c.process_batch(prev, nxt, smp, omega=omega, dt=dt, sky=sky, want_phi=True)
+        out2 = c.process_batch(prev, nxt, smp, omega=omega, dt=dt, sky=sky, want_phi=False)
+        flow = c.farneback(prev, nxt)
+    assert np.array_equal(out["flow"], flow)
+    assert np.array_equal(out["mask_fixed"], out2["mask_fixed"]) and np.array_equal(out["mask_dyn"], out2["mask_dyn"])
+    assert out["results"].tobytes() == out2["results"].tobytes()
+    for b in range(B):
+        ref = fo.run_chain(flow[b], smp[b], omega[b], dt[b], sky[b])
+        assert tuple(out["results"][b]["foe"]) == tuple(ref["foe"])
+        np.testing.assert_allclose(out["phi"][b], ref["phi"], rtol=0, atol=PHI_ATOL)
+        assert np.array_equal(out["mask_fixed"][b], ref["fixed"]) and np.array_equal(out["mask_dyn"][b], ref["total"])
+        assert tuple(out["results"][b]["box"]) == tuple(ref["box"])
