@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--group", type=int, default=0, help="pairs per launch (0 = library default)")
+    ap.add_argument("--group-fine", type=int, default=-1, help="pairs per launch for the finest layer's sweeps (-1 = library default)")
     ap.add_argument("--cpu-pairs", type=int, default=3, help="pairs in the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
@@ -84,6 +85,8 @@ def main():
     ctx = _lib.Context(W, H, B, device=local_rank)
     if args.group:
         ctx.set_option("group", args.group)
+    if args.group_fine >= 0:
+        ctx.set_option("group_fine", args.group_fine)
     layers = [ctx.layer_dims(k)[:2] for k in range(ctx.num_layers())]
 
     prev, nxt = synth.make_batch(W, H, B, distinct=4)
@@ -145,7 +148,8 @@ def main():
         run_batch()
         prof = ctx.profile_get()
         ctx.profile_enable(False)
-        ms, launches = prof["blur_iter"]
+        ms = prof["blur_iter"][0] + prof.get("blur_iter_coarse", (0.0, 0))[0]
+        launches = prof["blur_iter"][1] + prof.get("blur_iter_coarse", (0, 0))[1]
         iters = ctx.fb.iterations
         bytes_step = B * sum(w * h * ((iters - 1) * ITER_BYTES_UPDATE + ITER_BYTES_LAST) for (w, h) in layers)
         achieved = bytes_step / (ms * 1e-3) / 1e9

@@ -73,7 +73,8 @@ int mav_create(mav_ctx** out, int device, int W, int H, int max_batch, const mav
 int mav_destroy(mav_ctx*);
 const char* mav_last_error(void); /* thread-local, never NULL */
 int mav_device_count(void);       /* <= 0 when no GPU is visible */
-/* Tuning: name = "group" (pairs processed per launch, >= 1). Returns MAV_ERR_ARG for unknown names. */
+/* Tuning: "group" = pairs per launch (>= 1, default 8); "group_fine" = pairs per launch for the finest layer's sweeps
+ * (default 1: one pair's working set stays in the Infinity Cache; 0 = same as group). MAV_ERR_ARG for unknown names. */
 int mav_set_option(mav_ctx*, const char* name, long value);
 int mav_num_layers(const mav_ctx*);
 int mav_layer_dims(const mav_ctx*, int k, int* w, int* h, int* ksize, double* sigma);

@@ -9,6 +9,8 @@
 // The path is HBM/LDS-bound stencil work: no MFMA.
 #include "mavflow_internal.h"
 
+#include <stdlib.h>
+
 static __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -440,38 +442,97 @@ __global__ __launch_bounds__(256) void k_blur_iter_generic(const float* __restri
 // Fast form of the sweep for a compile-time half-window M_T (winsize 12 -> 6), image width a multiple of 4.
 // Tile = 64 x 16 pixels per 256-thread workgroup; tiles are numbered so that the workgroups one XCD receives
 // (blockIdx % 8, round-robin dispatch) walk one contiguous band of the image: halo rows are re-read from that XCD's L2.
-//   phase A  one thread per (plane, tile column): the 16+2m rows of its column come straight from HBM/L2 into
-//            registers (lanes = consecutive columns: coalesced row segments, all loads independent); the vertical
-//            sliding sums are formed in registers and only those 16 sums are written to LDS
-//   barrier
+// The kernel is built around memory latency (the v1-v3 profiles showed ~7 serialized round trips per tile):
+//   entry    the R0 values phase C will need are requested first (they depend on nothing)
+//   phase A  one thread per (plane, PAIR of tile columns): the 16+2m rows of its two columns arrive as float2 loads, all
+//            independent and in flight together; vertical sliding sums in registers; only the 16 sums go to LDS
+//   barrier  (the only one)
 //   phase B  one thread per 4 consecutive pixels of a row.  Lanes are assigned by the hardware's ds_read_b128 lane
 //            groups ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32): each group reads 16 consecutive float4 of ONE row =
-//            all 64 banks once, so the 4 reads per plane are conflict-free at any pitch.  Horizontal sliding sums in
-//            registers, 2x2 solve, flow -> HBM (float4 x2) and -> LDS
-//   barrier
-//   phase C  UpdateMatrices with lane = pixel column (64 consecutive pixels per wave): R0 loads, the 20 R1 gather
-//            loads and the 5 M' stores are all row-contiguous across the wave
-// LDS: 5 x 16 x 76 floats of vertical sums + 16 x 64 float2 of flow = 32.5 KB -> 4 workgroups per CU.  Raw M never
-// touches LDS.
+//            all 64 banks once, conflict-free at any pitch.  Horizontal sliding sums, 2x2 solve.  Wave v owns tile rows
+//            4v..4v+3 in phases B and C, and nobody else reads those LDS rows, so it parks its flow in the rows of planes
+//            0/1 it has just finished reading: no second barrier, no extra LDS.
+//   phase C  UpdateMatrices with lane = pixel column (64 consecutive pixels per wave): the R1 gathers of two pixels
+//            are in flight together; R0 loads, gathers and M' stores are all row-contiguous across the wave.
+// flow is stored to HBM only by a layer's last sweep (earlier sweeps' flow is consumed inside the kernel).
+// LDS: 5 x (16 x 76 + 12) floats = 24.6 KB -> 6 workgroups (24 waves) per CU.  Raw M never touches LDS.
 // ------------------------------------------------------------------------------------------------------------
 #define FT_X 64
 #define FT_Y 16
+
+struct GatherPx {
+    float p00[5], p01[5], p10[5], p11[5];
+    float fx, fy;
+    bool inside;
+};
+// request the 2x2 neighbourhood of the 5 R1 planes around (x + dx, y + dy); out-of-image taps read a clamped address
+static __device__ __forceinline__ void gather_issue(const float* __restrict__ R1p, size_t npx, int w, int h, int x, int y, float dx,
+                                                    float dy, GatherPx& g)
+{
+    float fx = x + dx, fy = y + dy;
+    const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
+    g.fx = fx - x1; g.fy = fy - y1;
+    g.inside = (unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1);
+    const int xc = g.inside ? x1 : 0, yc = g.inside ? y1 : 0;
+    const float* p = R1p + (size_t)yc * w + xc;
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        g.p00[c] = p[0]; g.p01[c] = p[1]; g.p10[c] = p[w]; g.p11[c] = p[w + 1];
+        p += npx;
+    }
+}
+static __device__ __forceinline__ void update_finish(const float q[5], const GatherPx& g, int w, int h, int x, int y, float dx,
+                                                     float dy, float out[5])
+{
+    float r2, r3, r4, r5, r6;
+    if (g.inside) {
+        const float a00 = (1.f - g.fx) * (1.f - g.fy), a01 = g.fx * (1.f - g.fy), a10 = (1.f - g.fx) * g.fy, a11 = g.fx * g.fy;
+        r2 = a00 * g.p00[0] + a01 * g.p01[0] + a10 * g.p10[0] + a11 * g.p11[0];
+        r3 = a00 * g.p00[1] + a01 * g.p01[1] + a10 * g.p10[1] + a11 * g.p11[1];
+        r4 = a00 * g.p00[2] + a01 * g.p01[2] + a10 * g.p10[2] + a11 * g.p11[2];
+        r5 = a00 * g.p00[3] + a01 * g.p01[3] + a10 * g.p10[3] + a11 * g.p11[3];
+        r6 = a00 * g.p00[4] + a01 * g.p01[4] + a10 * g.p10[4] + a11 * g.p11[4];
+        r4 = (q[2] + r4) * 0.5f;
+        r5 = (q[3] + r5) * 0.5f;
+        r6 = (q[4] + r6) * 0.25f;
+    } else {
+        r2 = r3 = 0.f;
+        r4 = q[2]; r5 = q[3]; r6 = q[4] * 0.5f;
+    }
+    r2 = (q[0] - r2) * 0.5f;
+    r3 = (q[1] - r3) * 0.5f;
+    r2 += r4 * dy + r6 * dx;
+    r3 += r6 * dy + r5 * dx;
+    const int BORDER = 5;
+    if ((unsigned)(x - BORDER) >= (unsigned)(w - BORDER * 2) || (unsigned)(y - BORDER) >= (unsigned)(h - BORDER * 2)) {
+        auto bw = [](int d) { return d < 2 ? 0.14f : 0.4472f; };
+        const float scale = (x < BORDER ? bw(x) : 1.f) * (x >= w - BORDER ? bw(w - x - 1) : 1.f) *
+                            (y < BORDER ? bw(y) : 1.f) * (y >= h - BORDER ? bw(h - y - 1) : 1.f);
+        r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
+    }
+    out[0] = r4 * r4 + r6 * r6;
+    out[1] = (r4 + r5) * r6;
+    out[2] = r5 * r5 + r6 * r6;
+    out[3] = r4 * r2 + r6 * r3;
+    out[4] = r6 * r2 + r5 * r3;
+}
+
 template <int M_T>
 __global__ __launch_bounds__(256) void k_blur_iter_fast(const float* __restrict__ M_in, float* __restrict__ M_out,
                                                         size_t M_stride, const float* __restrict__ R0,
                                                         const float* __restrict__ R1, size_t R_stride, int w, int h,
                                                         int tiles_x, int tiles_per_img, int n_tiles, float scale,
-                                                        int do_update, float* __restrict__ flow, size_t f_stride)
+                                                        int do_update, int store_flow, float* __restrict__ flow, size_t f_stride, int dbg)
 {
     constexpr int EXT_X = FT_X + 2 * M_T;              // 76
     constexpr int EXT_Y = FT_Y + 2 * M_T;              // 28
     constexpr int WIN = 2 * M_T + 1;                   // 13
     constexpr int PITCH = (EXT_X + 3) & ~3;            // 76
     constexpr int PLANE = FT_Y * PITCH + (EXT_X - (FT_Y * PITCH) % 32 + 64) % 32;   // = EXT_X (mod 32): phase-A lanes stay on distinct banks across planes
-    static_assert(PLANE % 4 == 0, "plane must keep 16-byte alignment");
+    static_assert(PLANE % 4 == 0 && EXT_X % 2 == 0, "plane must keep 16-byte alignment");
     __shared__ __attribute__((aligned(16))) float vs[5 * PLANE];
-    __shared__ __attribute__((aligned(16))) float2 fl[FT_Y * FT_X];
     const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
     // XCD-aware tile order: workgroups b, b+8, b+16, ... (one XCD) take consecutive tiles of one band
     const int nb = gridDim.x;
     const int per = (nb + 7) >> 3;
@@ -483,34 +544,70 @@ __global__ __launch_bounds__(256) void k_blur_iter_fast(const float* __restrict_
     const int x0 = tx * FT_X, y0 = ty * FT_Y;
     const size_t npx = (size_t)w * h;
     const float* Min = M_in + (size_t)s * M_stride;
+    const float* R0p = R0 + (size_t)s * R_stride;
+    const float* R1p = R1 + (size_t)s * R_stride;
 
-    for (int t = tid; t < 5 * EXT_X; t += 256) {
-        const int c = t / EXT_X, lx = t - c * EXT_X;
-        const int gx = clampi(x0 - M_T + lx, 0, w - 1);
-        const float* col = Min + c * npx + gx;
-        float v[EXT_Y];
+    // entry: R0 of this thread's four phase-C pixels (rows 4*wv + j, column lane)
+    float q[4][5];
+    int gys[4];
+    const int gxc = min(x0 + lane, w - 1);
+    if (do_update) {
 #pragma unroll
-        for (int i = 0; i < EXT_Y; i++) v[i] = col[(size_t)clampi(y0 - M_T + i, 0, h - 1) * w];
-        float* out = vs + c * PLANE + lx;
-        float sum = 0.f;
+        for (int j = 0; j < 4; j++) {
+            gys[j] = min(y0 + wv * 4 + j, h - 1);
+            const size_t idx = (size_t)gys[j] * w + gxc;
 #pragma unroll
-        for (int i = 0; i < WIN; i++) sum += v[i];
-        out[0] = sum;
+            for (int c = 0; c < 5; c++) q[j][c] = R0p[c * npx + idx];
+        }
+    }
+
+    if (x0 >= M_T && x0 + FT_X + M_T <= w) {           // all 76 columns inside the image: float2 columns, one pass
+        constexpr int NP = EXT_X / 2;                  // 38 column pairs per plane, 190 threads busy
+        for (int t = tid; t < 5 * NP; t += 256) {
+            const int c = t / NP, pr = t - c * NP;
+            const float* col = Min + c * npx + (x0 - M_T + 2 * pr);
+            float2 v[EXT_Y];
 #pragma unroll
-        for (int y = 1; y < FT_Y; y++) {
-            sum += v[y + WIN - 1] - v[y - 1];
-            out[y * PITCH] = sum;
+            for (int i = 0; i < EXT_Y; i++)
+                v[i] = (dbg & 1) ? make_float2((float)i, (float)pr) : *(const float2*)(col + (size_t)clampi(y0 - M_T + i, 0, h - 1) * w);
+            float* out = vs + c * PLANE + 2 * pr;
+            float sx = 0.f, sy = 0.f;
+#pragma unroll
+            for (int i = 0; i < WIN; i++) { sx += v[i].x; sy += v[i].y; }
+            *(float2*)out = make_float2(sx, sy);
+#pragma unroll
+            for (int y = 1; y < FT_Y; y++) {
+                sx += v[y + WIN - 1].x - v[y - 1].x;
+                sy += v[y + WIN - 1].y - v[y - 1].y;
+                *(float2*)(out + y * PITCH) = make_float2(sx, sy);
+            }
+        }
+    } else {                                           // tiles touching the left/right image edge: clamped scalar columns
+        for (int t = tid; t < 5 * EXT_X; t += 256) {
+            const int c = t / EXT_X, lx = t - c * EXT_X;
+            const int gx = clampi(x0 - M_T + lx, 0, w - 1);
+            const float* col = Min + c * npx + gx;
+            float v[EXT_Y];
+#pragma unroll
+            for (int i = 0; i < EXT_Y; i++) v[i] = col[(size_t)clampi(y0 - M_T + i, 0, h - 1) * w];
+            float* out = vs + c * PLANE + lx;
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < WIN; i++) sum += v[i];
+            out[0] = sum;
+#pragma unroll
+            for (int y = 1; y < FT_Y; y++) {
+                sum += v[y + WIN - 1] - v[y - 1];
+                out[y * PITCH] = sum;
+            }
         }
     }
     __syncthreads();
 
-    const int lane = tid & 63, wv = tid >> 6;
     {
-        // hardware b128 lane group and position inside it
-        const int l5 = lane & 31;
-        const int grp = (lane >> 5) * 2 + (((l5 >> 2) == 1 || (l5 >> 2) == 2 || (l5 >> 2) == 4 || (l5 >> 2) == 7) ? 1 : 0);
-        // groups (quads of 4 lanes): g0 = quads {0,3,5,6}, g1 = quads {1,2,4,7}
-        const int quad = l5 >> 2;
+        // hardware b128 lane group (quads of 4 lanes: g0 = quads {0,3,5,6}, g1 = quads {1,2,4,7}, +2 for lanes 32..63)
+        const int quad = (lane & 31) >> 2;
+        const int grp = (lane >> 5) * 2 + ((quad == 1 || quad == 2 || quad == 4 || quad == 7) ? 1 : 0);
         const int qpos = (quad == 0 || quad == 1) ? 0 : ((quad == 3 || quad == 2) ? 1 : ((quad == 5 || quad == 4) ? 2 : 3));
         const int pos = qpos * 4 + (lane & 3);          // 0..15 inside the group
         const int ly = wv * 4 + grp;                     // tile row 0..15
@@ -524,8 +621,8 @@ __global__ __launch_bounds__(256) void k_blur_iter_fast(const float* __restrict_
             float f[4 * NV];
 #pragma unroll
             for (int k = 0; k < NV; k++) {
-                const float4 q = p[k];
-                f[4 * k] = q.x; f[4 * k + 1] = q.y; f[4 * k + 2] = q.z; f[4 * k + 3] = q.w;
+                const float4 t4 = p[k];
+                f[4 * k] = t4.x; f[4 * k + 1] = t4.y; f[4 * k + 2] = t4.z; f[4 * k + 3] = t4.w;
             }
             float a = 0.f;
 #pragma unroll
@@ -541,47 +638,45 @@ __global__ __launch_bounds__(256) void k_blur_iter_fast(const float* __restrict_
 #pragma unroll
         for (int j = 0; j < 4; j++)
             solve_px(S[0][j] * scale, S[1][j] * scale, S[2][j] * scale, S[3][j] * scale, S[4][j] * scale, &u[j], &v[j]);
-        if (gx < w && gy < h) {                          // w % 4 == 0: the 4 pixels are all inside or all outside
+        if (store_flow && gx < w && gy < h) {            // w % 4 == 0: the 4 pixels are all inside or all outside
             float* fo = flow + (size_t)s * f_stride + ((size_t)gy * w + gx) * 2;
             *(float4*)fo = make_float4(u[0], v[0], u[1], v[1]);
             *(float4*)(fo + 4) = make_float4(u[2], v[2], u[3], v[3]);
         }
-        if (do_update) {
-            float4* fp = (float4*)(fl + ly * FT_X + lx0);
-            fp[0] = make_float4(u[0], v[0], u[1], v[1]);
-            fp[1] = make_float4(u[2], v[2], u[3], v[3]);
-        }
+        if (!do_update) return;
+        // park the flow in this wave's own rows of planes 0 (u) and 1 (v); every read of those rows by this wave is
+        // older in program order, and no other wave touches them
+        *(float4*)(vs + ly * PITCH + lx0) = make_float4(u[0], u[1], u[2], u[3]);
+        *(float4*)(vs + PLANE + ly * PITCH + lx0) = make_float4(v[0], v[1], v[2], v[3]);
     }
-    if (!do_update) return;
-    __syncthreads();
+    if (dbg & 2) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    const float* R0p = R0 + (size_t)s * R_stride;
-    const float* R1p = R1 + (size_t)s * R_stride;
     float* Mo = M_out + (size_t)s * M_stride;
-    const int gx = x0 + lane;
-    if (gx >= w) return;
-    // all four pixels' loads are issued before any of their arithmetic: rows past the image are clamped for the
-    // loads and only their stores are skipped
-    float q[4][5], fu[4], fv[4];
-    int gys[4];
+    const bool colok = x0 + lane < w;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int ly = wv * 4 + j;
-        gys[j] = min(y0 + ly, h - 1);
-        const float2 f = fl[ly * FT_X + lane];
-        fu[j] = f.x; fv[j] = f.y;
-        const size_t idx = (size_t)gys[j] * w + gx;
+    for (int jb = 0; jb < 4; jb += 2) {
+        GatherPx g[2];
+        float fu[2], fv[2];
 #pragma unroll
-        for (int c = 0; c < 5; c++) q[j][c] = R0p[c * npx + idx];
-    }
+        for (int jj = 0; jj < 2; jj++) {
+            const int ly = wv * 4 + jb + jj;
+            fu[jj] = vs[ly * PITCH + lane];
+            fv[jj] = vs[PLANE + ly * PITCH + lane];
+            if (dbg & 4) fu[jj] = 1e9f;
+            gather_issue(R1p, npx, w, h, gxc, gys[jb + jj], fu[jj], fv[jj], g[jj]);
+        }
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        float o[5];
-        update_core(q[j], R1p, npx, w, h, gx, gys[j], fu[j], fv[j], o);
-        if (y0 + wv * 4 + j < h) {
-            const size_t idx = (size_t)gys[j] * w + gx;
+        for (int jj = 0; jj < 2; jj++) {
+            float o[5];
+            update_finish(q[jb + jj], g[jj], w, h, gxc, gys[jb + jj], fu[jj], fv[jj], o);
+            if (colok && y0 + wv * 4 + jb + jj < h && !(dbg & 8)) {
+                const size_t idx = (size_t)gys[jb + jj] * w + gxc;
 #pragma unroll
-            for (int c = 0; c < 5; c++) Mo[c * npx + idx] = o[c];
+                for (int c = 0; c < 5; c++) Mo[c * npx + idx] = o[c];
+            }
         }
     }
 }
@@ -589,7 +684,7 @@ __global__ __launch_bounds__(256) void k_blur_iter_fast(const float* __restrict_
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 void launch_blur_iter(hipStream_t st, const float* M_in, float* M_out, size_t M_stride, const float* R0, const float* R1,
-                      size_t R_stride, int G, int w, int h, int winsize, int do_update, float* flow, size_t f_stride)
+                      size_t R_stride, int G, int w, int h, int winsize, int do_update, int store_flow, float* flow, size_t f_stride)
 {
     int ext, pitch, plane;
     const int m = winsize / 2;
@@ -597,12 +692,13 @@ void launch_blur_iter(hipStream_t st, const float* M_in, float* M_out, size_t M_
     dim3 grid((w + MAV_TILE - 1) / MAV_TILE, (h + MAV_TILE - 1) / MAV_TILE, G);
     const bool vec_ok = (w % 4 == 0) && (M_stride % 4 == 0) && (R_stride % 4 == 0) && (f_stride % 4 == 0) && aligned16(M_in) &&
                         aligned16(M_out) && aligned16(R0) && aligned16(R1) && aligned16(flow);
+    static const int dbg = getenv("MAVFLOW_DBG") ? atoi(getenv("MAVFLOW_DBG")) : 0;   // ablation switches (diagnostics only)
     if (m == 6 && vec_ok) {
         const int tiles_x = (w + FT_X - 1) / FT_X, tiles_y = (h + FT_Y - 1) / FT_Y;
         const int per_img = tiles_x * tiles_y, n_tiles = per_img * G;
         const int nb = ((n_tiles + 7) / 8) * 8;        // the XCD-aware renumbering needs a multiple of 8 workgroups
         hipLaunchKernelGGL(k_blur_iter_fast<6>, dim3(nb), dim3(256), 0, st, M_in, M_out, M_stride, R0, R1, R_stride, w, h,
-                           tiles_x, per_img, n_tiles, scale, do_update, flow, f_stride);
+                           tiles_x, per_img, n_tiles, scale, do_update, store_flow, flow, f_stride, dbg);
         return;
     }
     iter_geometry(m, &ext, &pitch, &plane);

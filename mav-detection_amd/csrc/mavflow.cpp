@@ -195,13 +195,13 @@ struct Layer {
     float *xw = nullptr, *yw = nullptr;
 };
 
-enum KernelId { K_BLUR_RESIZE, K_POLYEXP, K_UPDATE, K_ITER, K_FOE, K_PHI, K_MISC, K_COUNT };
-static const char* const kKernelNames[K_COUNT] = {"blur_resize", "polyexp", "update_matrices", "blur_iter",
+enum KernelId { K_BLUR_RESIZE, K_POLYEXP, K_UPDATE, K_ITER, K_ITER_COARSE, K_FOE, K_PHI, K_MISC, K_COUNT };
+static const char* const kKernelNames[K_COUNT] = {"blur_resize", "polyexp", "update_matrices", "blur_iter", "blur_iter_coarse",
                                                   "foe_ransac", "phi_mask_box", "misc"};
 struct ProfRec { int kid; hipEvent_t a, b; };
 
 struct mav_ctx {
-    int device = 0, W = 0, H = 0, max_batch = 0, group = 0;
+    int device = 0, W = 0, H = 0, max_batch = 0, group = 0, group_fine = 1;
     mav_fb_params fb;
     hipStream_t stream = nullptr;
     std::vector<Layer> layers;
@@ -341,10 +341,12 @@ extern "C" int mav_create(mav_ctx** out, int device, int W, int H, int max_batch
     }
     c->n0 = (size_t)W * H;
     c->n1 = levels >= 1 ? (size_t)c->layers[1].w * c->layers[1].h : 0;
-    // group: pairs per launch.  Default keeps ~2 pairs of the full-resolution iteration working set in flight; the
-    // caller can raise it with mav_set_option("group").
-    int group = max_batch < 2 ? max_batch : 2;
+    // group: pairs per launch for everything but the finest layer's sweeps (see farneback_group).
+    int group = max_batch < 8 ? max_batch : 8;
     if (const char* e = getenv("MAVFLOW_GROUP")) { int v = atoi(e); if (v >= 1) group = v < max_batch ? v : max_batch; }
+    if (const char* e = getenv("MAVFLOW_GROUP_FINE")) { int v = atoi(e); if (v >= 0) c->group_fine = v; }
+    // the Infinity-Cache argument only holds while one pair's finest-layer working set (80 B/px) fits in it
+    if ((size_t)W * H * 80 > (size_t)200 << 20) c->group_fine = 0;
     rc = alloc_group(c, group);
     if (rc != MAV_OK) return bail(rc);
     const size_t B = (size_t)max_batch;
@@ -369,6 +371,11 @@ extern "C" int mav_set_option(mav_ctx* c, const char* name, long value)
         HIPCHK(hipSetDevice(c->device));
         HIPCHK(hipStreamSynchronize(c->stream));
         return g == c->group ? MAV_OK : alloc_group(c, g);
+    }
+    if (!strcmp(name, "group_fine")) {
+        if (value < 0) return fail(MAV_ERR_ARG, "group_fine must be >= 0 (0 = same as group)");
+        c->group_fine = (int)value;
+        return MAV_OK;
     }
     return fail(MAV_ERR_ARG, "unknown option '%s'", name);
 }
@@ -498,12 +505,20 @@ static int farneback_group(mav_ctx* c, const uint8_t* prev, const uint8_t* next,
                                  l.w, l.h, c->Ma, 5 * n0); }
         float* fdst = k > 0 ? c->fc[k & 1] : flow_out;
         const size_t fstride = k > 0 ? fc_stride : 2 * n0;
-        float *Min = c->Ma, *Mout = c->Mb;
-        for (int it = 0; it < c->fb.iterations; it++) {
-            const int upd = it < c->fb.iterations - 1;
-            { ProfScope ps(c, K_ITER);
-              launch_blur_iter(c->stream, Min, Mout, 5 * n0, c->R0, c->R1, 5 * n0, g, l.w, l.h, c->fb.winsize, upd, fdst, fstride); }
-            if (upd) { float* t = Min; Min = Mout; Mout = t; }
+        // The finest layer's ten sweeps re-read R0/R1 and ping-pong M: run them `group_fine` pairs at a time so that
+        // one sub-group's working set (166 MB per 1080p pair) stays resident in the 256 MB Infinity Cache between
+        // sweeps.  Coarse layers are small: all g pairs per launch to fill the 256 CUs.
+        const int sub = (k == 0 && c->group_fine > 0 && c->group_fine < g) ? c->group_fine : g;
+        for (int s0 = 0; s0 < g; s0 += sub) {
+            const int gs = g - s0 < sub ? g - s0 : sub;
+            float *Min = c->Ma + (size_t)s0 * 5 * n0, *Mout = c->Mb + (size_t)s0 * 5 * n0;
+            for (int it = 0; it < c->fb.iterations; it++) {
+                const int upd = it < c->fb.iterations - 1;
+                { ProfScope ps(c, k == 0 ? K_ITER : K_ITER_COARSE);
+                  launch_blur_iter(c->stream, Min, Mout, 5 * n0, c->R0 + (size_t)s0 * 5 * n0, c->R1 + (size_t)s0 * 5 * n0, 5 * n0, gs,
+                                   l.w, l.h, c->fb.winsize, upd, !upd, fdst + (size_t)s0 * fstride, fstride); }
+                if (upd) { float* t = Min; Min = Mout; Mout = t; }
+            }
         }
         flow_prev = fdst; pw = l.w; ph = l.h;
     }
@@ -843,7 +858,7 @@ extern "C" int mav_stage_blur_iter(mav_ctx* c, const float* R0, const float* R1,
     CHK(d0.upload(c, R0, 5 * n * sizeof(float))); CHK(d1.upload(c, R1, 5 * n * sizeof(float)));
     CHK(dm.upload(c, M, 5 * n * sizeof(float))); CHK(dmo.alloc(5 * n * sizeof(float))); CHK(df.alloc(2 * n * sizeof(float)));
     launch_blur_iter(c->stream, dm.as<float>(), dmo.as<float>(), 5 * n, d0.as<float>(), d1.as<float>(), 5 * n, 1, l->w, l->h,
-                     c->fb.winsize, update, df.as<float>(), 2 * n);
+                     c->fb.winsize, update, 1, df.as<float>(), 2 * n);
     CHK(check_launch("blur_iter"));
     CHK(download(c, flow, df.p, 2 * n * sizeof(float)));
     if (update) CHK(download(c, M_out, dmo.p, 5 * n * sizeof(float)));

@@ -44,7 +44,8 @@ void launch_update_matrices(hipStream_t st, const float* R0, const float* R1, si
 void launch_update_matrices_flow(hipStream_t st, const float* R0, const float* R1, size_t R_stride, const float* flow,
                                  size_t f_stride, int G, int w, int h, float* M, size_t M_stride);
 void launch_blur_iter(hipStream_t st, const float* M_in, float* M_out, size_t M_stride, const float* R0, const float* R1,
-                      size_t R_stride, int G, int w, int h, int winsize, int do_update, float* flow, size_t f_stride);
+                      size_t R_stride, int G, int w, int h, int winsize, int do_update, int store_flow, float* flow, size_t f_stride);
+// store_flow == 0: the sweep's flow is consumed inside the kernel only (valid when do_update != 0)
 size_t blur_iter_lds_bytes(int winsize);
 
 // ---- detection kernels (kernels_detect.hip, compiled with -ffp-contract=off) --------------------------------
