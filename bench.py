@@ -74,9 +74,12 @@ def main():
     if world > 1 or os.environ.get("MAVFLOW_BENCH_DIST") == "1":
         # torch first: libmavflow then binds to the HIP runtime torch already loaded (same SONAME), one runtime per process
         import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        from mavflow import dist as mdist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        dist, rank, world, local_rank = mdist.init_process_group("nccl")
 
     import numpy as np
     from mavflow import _lib, synth
@@ -117,7 +120,7 @@ def main():
         run_batch()
         if dist is not None:
             ctx.sync()
-            dist.all_gather_into_tensor(t_all, t_local)
+            mdist.allgather_records(dist, t_local, t_all)
 
     def barrier():
         ctx.sync()

@@ -1,0 +1,191 @@
+"""Processor -- the detection loop of /root/reference/src/processor.py:277-396 (FoE branch) on libmavflow.
+
+run_detection() keeps the reference's shape: one frame index at a time, the same order of operations
+(:305-341), the same FrameResult fields (:353-362).  run_detection_batched() is the MI355X form of the same loop:
+frame pairs are independent once the flow no longer comes from files, so they go through the fused
+mav_process_batch entry point `batch` pairs at a time.  File / video / PNG output and the homography branch are
+outside the hot path and are not reproduced."""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+from . import _lib, im_helpers, synth, utils
+from .detector import Detector
+from .focus_of_expansion import FocusOfExpansion
+from .frame_result import FrameResult
+from .run_config import RunConfig
+
+
+class SyntheticDataset:
+    """A dataset object with the getters run_detection uses (datasets/dataset.py:152-344), fed by mavflow.synth: a textured
+    scene under radial (FoE) motion plus one 24x24 patch moving against it.  Flow comes from libmavflow's Farneback
+    (use_farneback=True, the seam this build adds) or from the analytic field (the reference's .flo seam)."""
+
+    def __init__(self, W: int = 640, H: int = 480, N: int = 6, use_farneback: bool = True, dt: float = 1 / 30.0,
+                 dangle=(0.0, 0.0, 0.0), seed: int = 0):
+        self.capture_size = (W, H)
+        self.resolution = np.array([W, H])
+        self.N = N
+        self.sequence = f"synthetic-{seed}"
+        self.use_farneback = use_farneback
+        self.dt = dt
+        self.dangle = np.asarray(dangle, np.float64)
+        self.seed = seed
+        self._pairs = {}
+        self._ctx: Optional[_lib.Context] = None
+        self._frame_cursor = 0
+
+    def _pair(self, i: int):
+        if i not in self._pairs:
+            self._pairs[i] = synth.make_pair(self.capture_size[0], self.capture_size[1], self.seed * 1000 + i)
+        return self._pairs[i]
+
+    def frame_pair(self, i: int) -> Tuple[np.ndarray, np.ndarray]:
+        f0, f1, _ = self._pair(i)
+        return f0, f1
+
+    def get_frame(self) -> np.ndarray:
+        f = self._pair(self._frame_cursor)[1]
+        self._frame_cursor += 1
+        return np.repeat(f[..., None], 3, axis=2)
+
+    def get_flow_uv(self, i: int) -> np.ndarray:
+        f0, f1, truth = self._pair(i)
+        if not self.use_farneback:
+            return truth.astype(np.float32)
+        if self._ctx is None:
+            self._ctx = _lib.Context(self.capture_size[0], self.capture_size[1], 1)
+        return self._ctx.farneback(f0, f1)[0]
+
+    def get_gt_of(self, i: int) -> np.ndarray:
+        return self._pair(i)[2].astype(np.float32)
+
+    def get_segmentation(self, i: int) -> np.ndarray:
+        W, H = self.capture_size
+        seg = np.zeros((H, W, 3), np.uint8)
+        seg[H // 4:H // 4 + 24, W // 4:W // 4 + 24] = 255
+        return seg
+
+    def get_sky_segmentation(self, i: int) -> np.ndarray:
+        return np.zeros((self.capture_size[1], self.capture_size[0]), dtype=bool)
+
+    def get_depth(self, i: int) -> np.ndarray:
+        return np.ones((self.capture_size[1], self.capture_size[0]), np.float32)
+
+    def validate_sky_segment(self, sky_mask, depth_buffer) -> Tuple[float, float]:
+        return (0.0, 0.0)
+
+    def get_gt_foe(self, i: int) -> Tuple[float, float]:
+        return (0.55 * self.capture_size[0], 0.45 * self.capture_size[1])
+
+    def get_time(self, i: int) -> float:
+        return i * self.dt
+
+    def get_delta_time(self, i: int) -> float:
+        return self.dt
+
+    def get_angular_difference(self, a: int, b: int) -> np.ndarray:
+        return self.dangle
+
+    def release(self) -> None:
+        if self._ctx is not None:
+            self._ctx.close()
+            self._ctx = None
+
+
+class Processor:
+    def __init__(self, config: RunConfig) -> None:
+        self.config = config
+        self.logger = config.logger
+        self.sequence = config.sequence
+        self.debug_mode = config.debug
+        self.headless = config.headless
+        self.dataset = config.get_dataset()
+        self.detector = Detector(self.dataset)
+        self.detection_results: Dict[int, FrameResult] = dict()
+        self.frame_step_size = 1
+        self.frame_index, self.start_frame = 0, 100
+        self.is_exiting = False
+        self.focus_of_expansion = FocusOfExpansion(self.detector.lucas_kanade)
+
+    def is_active(self) -> bool:
+        return self.frame_index < self.dataset.N - 1 and not self.is_exiting
+
+    # -- validation tail shared by both loops (processor.py:343-362) --------------------------------------------------
+    def _fill_result(self, i: int, foe_dense, derotated, gt_derotated, estimate_fixed, total_mask, sky_scores) -> FrameResult:
+        r = FrameResult()
+        r.foe_dense = foe_dense
+        r.foe_gt = utils.assert_type(self.dataset.get_gt_foe(i))
+        segmentation = self.dataset.get_segmentation(i)[..., 0]
+        with np.errstate(all="ignore"):
+            drone_flow_avg_gt = np.average(gt_derotated[segmentation > 127], axis=0)
+        center = im_helpers.get_simple_bounding_box(segmentation).get_center()
+        r.center_phi = np.rad2deg(np.arctan2(center[1] - r.foe_gt[1], center[0] - r.foe_gt[0]))
+        r.tpr_fixed, r.fpr_fixed = im_helpers.calculate_tpr_fpr(segmentation, estimate_fixed)
+        r.tpr, r.fpr = im_helpers.calculate_tpr_fpr(segmentation, total_mask)
+        r.sky_tpr, r.sky_fpr = sky_scores
+        r.drone_flow_pixels = (drone_flow_avg_gt[0], drone_flow_avg_gt[1])
+        r.drone_size_pixels = np.sum(segmentation > 127)
+        r.time = self.dataset.get_time(i)
+        return r
+
+    def run_detection(self) -> Dict[int, FrameResult]:
+        """One frame index at a time, staged calls, as the reference's loop body."""
+        while self.is_active():
+            i = self.frame_index
+            self.dataset.get_frame()
+            self.flow_uv = self.dataset.get_flow_uv(i)
+            if self.flow_uv is None:
+                raise ValueError("Could not load flow field.")
+            self.flow_uv_derotated = self.detector.derotate(i - self.frame_step_size, i, self.flow_uv)
+            self.gt_flow_uv = utils.assert_type(self.dataset.get_gt_of(i))
+            self.gt_flow_uv_derotated = self.detector.derotate(i - self.frame_step_size, i, self.gt_flow_uv)
+            self.sky_mask = self.dataset.get_sky_segmentation(i)
+            sky = self.dataset.validate_sky_segment(self.sky_mask, utils.assert_type(self.dataset.get_depth(i)))
+            foe = self.focus_of_expansion.get_FOE_dense(self.flow_uv_derotated)
+            fixed, total = self.focus_of_expansion.get_masks(self.flow_uv_derotated, foe, self.sky_mask)
+            self.estimate_fixed, self.total_mask = fixed, total
+            r = self._fill_result(i, foe, self.flow_uv_derotated, self.gt_flow_uv_derotated, fixed, total, sky)
+            self.detection_results[i] = r
+            self.config.results[i] = r
+            self.frame_index += 1
+        return self.detection_results
+
+    def run_detection_batched(self, batch: int = 8) -> Dict[int, FrameResult]:
+        """The same loop with frame pairs in flight `batch` at a time through the fused entry point (frames -> flow ->
+        derotation -> FoE -> masks -> box).  Needs a dataset that hands out frame pairs (frame_pair(i))."""
+        W, H = self.dataset.capture_size
+        idx = list(range(self.frame_index, self.dataset.N - 1))
+        with _lib.Context(W, H, batch) as ctx:
+            for b0 in range(0, len(idx), batch):
+                ids = idx[b0:b0 + batch]
+                prev = np.stack([self.dataset.frame_pair(i)[0] for i in ids])
+                nxt = np.stack([self.dataset.frame_pair(i)[1] for i in ids])
+                samples = np.zeros((len(ids), 2000, 2), np.uint32)
+                for k in range(len(ids)):                      # same draws, same order as get_FOE_dense
+                    samples[k, :, 0] = np.random.randint(0, H, 2000)
+                    samples[k, :, 1] = np.random.randint(0, W, 2000)
+                dts = np.array([self.dataset.get_delta_time(i) for i in ids], np.float64)
+                rot = [i >= 1 for i in ids]
+                omega = np.stack([np.asarray(self.dataset.get_angular_difference(i - 1, i), np.float64) / dt
+                                  for i, dt in zip(ids, dts)])
+                if not all(rot):                               # frame 0 is never derotated (detector.py:80-81)
+                    omega[[k for k, r_ in enumerate(rot) if not r_]] = 0.0
+                sky = np.stack([self.dataset.get_sky_segmentation(i) for i in ids])
+                out = ctx.process_batch(prev, nxt, samples, omega=omega, dt=dts, sky=sky)
+                for k, i in enumerate(ids):
+                    gt = utils.assert_type(self.dataset.get_gt_of(i))
+                    gt_der = self.detector.derotate(i - 1, i, gt)
+                    rec = out["results"][k]
+                    r = self._fill_result(i, (float(rec["foe"][0]), float(rec["foe"][1])), None, gt_der,
+                                          out["mask_fixed"][k], out["mask_dyn"][k], (0.0, 0.0))
+                    r.box = utils.Rectangle.from_box(rec["box"])   # extra: the detection box (the reference never stores one)
+                    self.detection_results[i] = r
+                    self.config.results[i] = r
+        self.frame_index = self.dataset.N - 1
+        return self.detection_results
+
+    def release(self) -> None:
+        self.dataset.release()

@@ -1,0 +1,148 @@
+"""The reference-shaped Python classes on the GPU path: same calls, same seeds, same answers as the fixtures the
+reference's own code produced (tests/golden) and as the oracle."""
+import logging
+
+import numpy as np
+import pytest
+
+from oracle import foe_oracle as fo
+from mavflow import synth
+
+pytestmark = pytest.mark.gpu
+PHI_ATOL = 4 * np.spacing(180.0)
+
+
+class FakeDataset:
+    def __init__(self, W, H, dangle, dt):
+        self.capture_size = (W, H)
+        self.dangle, self.dt = np.asarray(dangle, np.float64), dt
+
+    def get_delta_time(self, i):
+        return self.dt
+
+    def get_angular_difference(self, a, b):
+        return self.dangle
+
+
+def test_focus_of_expansion_seeded_like_the_reference(mav, golden):
+    from mavflow.detector import LucasKanade
+    from mavflow.focus_of_expansion import FocusOfExpansion
+    foe = FocusOfExpansion(LucasKanade(np.zeros((120, 160, 3), np.uint8)))
+    for c in range(4):
+        flow = golden["foe_flow"][c]
+        if golden["foe_flow_is_f32"][c]:
+            flow = flow.astype(np.float32)
+        np.random.seed(int(golden["foe_seed"][c]))
+        got = foe.get_FOE_dense(flow)
+        assert isinstance(got, tuple) and got == tuple(golden["foe_out"][c]), c
+        phi = foe.get_phi(golden["foe_flow"][c], got)
+        np.testing.assert_allclose(phi, golden["phi_out"][c], rtol=0, atol=PHI_ATOL)
+        assert abs(foe.max_flow - golden["phi_out"][c].max()) <= PHI_ATOL
+    assert foe.get_phi(golden["foe_flow"][0], (np.nan, np.nan)).shape == (0,)
+    fixed, total = foe.get_masks(golden["foe_flow"][1], tuple(golden["foe_out"][1]), golden["thr_sky"])
+    assert np.array_equal(fixed, golden["thr_sky_fixed"]) and np.array_equal(total, golden["thr_sky_total"])
+
+
+def test_constructors_consume_the_same_random_draws(mav):
+    """Detector / LucasKanade / FocusOfExpansion constructors must leave the global RNG where the reference leaves it."""
+    from mavflow.detector import Detector
+    from mavflow.focus_of_expansion import FocusOfExpansion
+    np.random.seed(7)
+    d = Detector(FakeDataset(160, 120, (0, 0, 0), 1.0))
+    FocusOfExpansion(d.lucas_kanade)
+    after = np.random.randint(0, 1 << 30)
+    np.random.seed(7)
+    np.random.randint(20, 100, 1000); np.random.randint(20, 140, 1000)          # detector.py:33-36
+    np.random.randint(0, 255, (2666, 3))                                          # lucas_kanade.py:32
+    np.random.randint(0, 255, (2666, 3)); np.random.randint(0, 2666, 2666)        # focus_of_expansion.py:24,26
+    assert after == np.random.randint(0, 1 << 30)
+
+
+def test_detector_derotate_and_window(mav, golden):
+    from mavflow.detector import Detector
+    dt = float(golden["derot_dt"])
+    d = Detector(FakeDataset(160, 120, golden["derot_dangle"], dt))
+    f = golden["derot_in"]
+    assert d.derotate(-1, 0, f) is f
+    out = d.derotate(0, 1, f)
+    assert out.dtype == np.float64 and out.tobytes() == golden["derot_out"].tobytes()
+    assert d.algorithm is Detector.Algorithm.ESSENTIAL and not d.is_homography_based()
+    img = np.zeros((120, 160), np.uint8)
+    img[40:60, 70:100] = 200
+    from mavflow import im_helpers
+    rgb = im_helpers.to_rgb(img.astype(np.float64), 255.0)
+    score, rect, window, amax = d.analyze_pyramid(rgb)
+    es, ex, ey = fo.analyze_pyramid_level0(rgb[..., 0])
+    assert (score, rect.topleft, rect.size) == (es, (ex, ey), (64, 64)) and window.shape == (64, 64, 3)
+    assert d.analyze_pyramid(np.zeros((120, 160, 3), np.uint8))[0] == 0
+
+
+def test_im_helpers_on_gpu(mav, golden):
+    from mavflow import im_helpers
+    r = im_helpers.get_simple_bounding_box(golden["bbox_a_in"])
+    assert [r.topleft[0], r.topleft[1], r.size[0], r.size[1]] == list(golden["bbox_a"])
+    r = im_helpers.get_simple_bounding_box(np.zeros((120, 160), np.uint8))
+    assert [r.topleft[0], r.topleft[1], r.size[0], r.size[1]] == list(golden["bbox_empty"])
+    got = im_helpers.calculate_tpr_fpr(golden["tpr_gt"], 255 * golden["thr_nosky_fixed"])
+    assert np.array(got, np.float64).tobytes() == golden["tpr_out"].tobytes()
+    mag = im_helpers.get_magnitude(golden["foe_flow"][1])
+    assert mag.tobytes() == golden["mag_out"].tobytes()
+
+
+class FakeCapture:
+    def __init__(self, frames):
+        self.frames, self.i = frames, 0
+
+    def read(self):
+        f = self.frames[min(self.i, len(self.frames) - 1)]
+        self.i += 1
+        return True, np.repeat(f[..., None], 3, axis=2)
+
+
+def test_farneback_class(mav, fb_oracle):
+    from mavflow.farneback import Farneback
+    f0, f1, _ = synth.make_pair(320, 240, 5)
+    black = np.zeros_like(f0)
+    fb = Farneback(FakeCapture([f0, f1, black, black]), None)
+    vis = fb.process()
+    assert vis.shape == (240, 320, 3) and vis.dtype == np.uint8
+    ref = fb_oracle.calc(f0, f1)
+    e = np.hypot(fb.flow[..., 0] - ref[..., 0], fb.flow[..., 1] - ref[..., 1])
+    assert e.mean() <= 1e-2 and np.percentile(e, 99.9) <= 1e-1
+    fb.process()                              # f1 -> black: some flow, new visualisation
+    vis_prev = fb.prev_result
+    vis2 = fb.process()                       # black -> black: constant (zero) magnitude = "invalid frame": previous result is kept
+    assert np.all(fb.flow == 0) and np.array_equal(vis2, vis_prev)
+
+
+def test_processor_loops_agree_with_the_oracle(mav):
+    from mavflow.processor import Processor, SyntheticDataset
+    from mavflow.run_config import RunConfig
+    W, H, N = 320, 240, 4
+    def make():
+        ds = SyntheticDataset(W, H, N, use_farneback=True, dangle=(0.004, -0.002, 0.001))
+        cfg = RunConfig(logging.getLogger("t"), ds, "", False, False, False, True, False, False, "FLOW_FOE_CLUSTERING")
+        np.random.seed(11)
+        return Processor(cfg), ds
+    p1, ds1 = make()
+    res = p1.run_detection()
+    p2, ds2 = make()
+    res_b = p2.run_detection_batched(batch=2)
+    assert sorted(res) == sorted(res_b) == [0, 1, 2]
+    # the oracle, fed the same flow and the same random draws
+    np.random.seed(11)
+    make()                                     # constructors consume their draws again
+    for i in range(N - 1):
+        smp = np.zeros((2000, 2), np.uint32)
+        smp[:, 0] = np.random.randint(0, H, 2000); smp[:, 1] = np.random.randint(0, W, 2000)
+        flow = ds1.get_flow_uv(i)
+        ref = fo.run_chain(flow, smp, ds1.dangle / ds1.dt, ds1.dt, None, current_frame_index=i)
+        for r in (res[i], res_b[i]):
+            assert r.foe_dense == ref["foe"], (i, r.foe_dense, ref["foe"])
+        seg = ds1.get_segmentation(i)[..., 0]
+        with np.errstate(all="ignore"):
+            exp = fo.calculate_tpr_fpr(seg, 255 * ref["fixed"])
+        assert (res[i].tpr_fixed, res[i].fpr_fixed) == tuple(exp) == (res_b[i].tpr_fixed, res_b[i].fpr_fixed)
+        assert res[i].drone_size_pixels == 24 * 24 and res[i].time == i * ds1.dt
+        assert tuple(int(v) for v in (res_b[i].box.topleft + res_b[i].box.size)) == \
+            (ref["box"][0], ref["box"][1], ref["box"][2] - ref["box"][0], ref["box"][3] - ref["box"][1])
