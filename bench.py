@@ -144,6 +144,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- PCIe-inclusive rate (never `value`): the same steps with the two u8 frame stacks uploaded inside the loop ----
+    h2d_ms = None
+    if rank == 0 and not args.no_profile:
+        ctx.sync()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            d_prev.upload(prev); d_next.upload(nxt)
+            run_batch()
+        ctx.sync()
+        h2d_ms = 1e3 * (time.perf_counter() - t1) / 2
+
     # ---- roofline of the dominant kernel (separate pass, HIP events around every launch on the context's stream) ----
     roofline = None
     if rank == 0 and not args.no_profile:
@@ -177,6 +188,8 @@ def main():
                "hip_event_ms_per_step": round(ev_ms / args.steps, 3),
                "pipeline_alg_bytes_per_pair": balg,
                "pipeline_frac_of_hbm_peak": round(value / world * balg / (HBM_PEAK_GBS * 1e9), 4)}
+        if h2d_ms:
+            out["value_incl_h2d"] = round(B / (h2d_ms * 1e-3), 2)
         if roofline:
             out["roofline"] = roofline
         if world == 1 and args.cpu_pairs > 0:
