@@ -74,7 +74,8 @@ int mav_destroy(mav_ctx*);
 const char* mav_last_error(void); /* thread-local, never NULL */
 int mav_device_count(void);       /* <= 0 when no GPU is visible */
 /* Tuning: "group" = pairs per launch (>= 1, default 8); "group_fine" = pairs per launch for the finest layer's sweeps
- * (default 1: one pair's working set stays in the Infinity Cache; 0 = same as group). MAV_ERR_ARG for unknown names. */
+ * (default 1: one pair's working set stays in the Infinity Cache; 0 = same as group); "recompute" = 1: sweeps rebuild M
+ * from (R0, R1, flow) on the fly instead of storing it (default 0). MAV_ERR_ARG for unknown names. */
 int mav_set_option(mav_ctx*, const char* name, long value);
 int mav_num_layers(const mav_ctx*);
 int mav_layer_dims(const mav_ctx*, int k, int* w, int* h, int* ksize, double* sigma);

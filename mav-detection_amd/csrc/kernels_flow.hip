@@ -276,6 +276,31 @@ static __device__ __forceinline__ void solve_px(float g11, float g12, float g22,
     *v = (fmaf(g22, h1, -qb) - qbe) * idet;
 }
 
+// resize(prevFlow -> layer size, INTER_LINEAR) * mul at one pixel (A.2): half-pixel centres, clamped, f32 weights.
+static __device__ __forceinline__ float2 upsample_flow(const float* __restrict__ pf, int pw, int ph, float mul, double scale_x,
+                                                       double scale_y, int x, int y)
+{
+    float fy = (float)((y + 0.5) * scale_y - 0.5);
+    int sy = (int)floorf(fy);
+    fy -= sy;
+    if (sy < 0) { fy = 0.f; sy = 0; }
+    if (sy >= ph - 1) { fy = 0.f; sy = ph - 1; }
+    const int sy1 = sy + 1 < ph ? sy + 1 : sy;
+    float fx = (float)((x + 0.5) * scale_x - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= sx;
+    if (sx < 0) { fx = 0.f; sx = 0; }
+    if (sx >= pw - 1) { fx = 0.f; sx = pw - 1; }
+    const int sx1 = sx + 1 < pw ? sx + 1 : sx;
+    const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
+    const float2 p00 = *(const float2*)(pf + ((size_t)sy * pw + sx) * 2);
+    const float2 p01 = *(const float2*)(pf + ((size_t)sy * pw + sx1) * 2);
+    const float2 p10 = *(const float2*)(pf + ((size_t)sy1 * pw + sx) * 2);
+    const float2 p11 = *(const float2*)(pf + ((size_t)sy1 * pw + sx1) * 2);
+    return make_float2(((p00.x * a0 + p01.x * a1) * b0 + (p10.x * a0 + p11.x * a1) * b1) * mul,
+                       ((p00.y * a0 + p01.y * a1) * b0 + (p10.y * a0 + p11.y * a1) * b1) * mul);
+}
+
 // Initial M of a layer.  flow = 0 (top layer), resize(prevFlow)*mul evaluated inline (lower layers), or an
 // explicit flow field (stage hook).  The upsampled flow is never written: the first blur sweep overwrites it.
 template <int MODE>  // 0 zero, 1 upsample, 2 explicit
@@ -290,26 +315,8 @@ __global__ __launch_bounds__(256) void k_update_matrices(const float* __restrict
     const int s = blockIdx.z;
     float dx = 0.f, dy = 0.f;
     if (MODE == 1) {
-        const float* pf = fsrc + (size_t)s * f_stride;
-        float fy = (float)((y + 0.5) * scale_y - 0.5);
-        int sy = (int)floorf(fy);
-        fy -= sy;
-        if (sy < 0) { fy = 0.f; sy = 0; }
-        if (sy >= ph - 1) { fy = 0.f; sy = ph - 1; }
-        const int sy1 = sy + 1 < ph ? sy + 1 : sy;
-        float fx = (float)((x + 0.5) * scale_x - 0.5);
-        int sx = (int)floorf(fx);
-        fx -= sx;
-        if (sx < 0) { fx = 0.f; sx = 0; }
-        if (sx >= pw - 1) { fx = 0.f; sx = pw - 1; }
-        const int sx1 = sx + 1 < pw ? sx + 1 : sx;
-        const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
-        const float2 p00 = *(const float2*)(pf + ((size_t)sy * pw + sx) * 2);
-        const float2 p01 = *(const float2*)(pf + ((size_t)sy * pw + sx1) * 2);
-        const float2 p10 = *(const float2*)(pf + ((size_t)sy1 * pw + sx) * 2);
-        const float2 p11 = *(const float2*)(pf + ((size_t)sy1 * pw + sx1) * 2);
-        dx = ((p00.x * a0 + p01.x * a1) * b0 + (p10.x * a0 + p11.x * a1) * b1) * mul;
-        dy = ((p00.y * a0 + p01.y * a1) * b0 + (p10.y * a0 + p11.y * a1) * b1) * mul;
+        const float2 f = upsample_flow(fsrc + (size_t)s * f_stride, pw, ph, mul, scale_x, scale_y, x, y);
+        dx = f.x; dy = f.y;
     } else if (MODE == 2) {
         const float2 f = *(const float2*)(fsrc + (size_t)s * f_stride + ((size_t)y * w + x) * 2);
         dx = f.x; dy = f.y;
@@ -681,6 +688,154 @@ __global__ __launch_bounds__(256) void k_blur_iter_fast(const float* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The sweep without an M array ("recompute" form).  The measured limit of k_blur_iter_fast is HBM bytes (80 B per pixel
+// and sweep, half of it M in / M' out), while its VALU sits at ~27 %.  M is a pointwise function of (R0, R1, flow), so
+// this kernel rebuilds it for the tile AND its 6-pixel halo (2.08x the UpdateMatrices arithmetic, served by L2 for the
+// halo) instead of storing and re-reading it: per pixel and sweep it moves R0 20 + R1 20 + flow-in 8 + flow-out 8 =
+// 56 B of HBM traffic, and the initial-M kernel of a layer disappears (the first sweep takes a zero / upsampled flow).
+//   phase 1  M for the 76 x 28 region -> LDS (5 planes): per pixel flow-in, R0, 2x2 R1 gather (two pixels in flight)
+//   phase 2  vertical sliding sums, float2 column pairs from LDS, written back in place (rows 0..15)
+//   phase 3  = phase B of k_blur_iter_fast: conflict-free b128 rows, horizontal sums, solve, flow -> HBM
+// LDS 43.8 KB -> 3 workgroups per CU.  Same algebra as the M-array form (results agree to f32 rounding noise).
+// ------------------------------------------------------------------------------------------------------------
+template <int M_T, int MODE>  // MODE 0: zero flow in, 1: upsampled coarse flow, 2: explicit flow (h, w, 2)
+__global__ __launch_bounds__(256) void k_sweep_rc(const float* __restrict__ fin, size_t fin_stride, int pw, int ph, float mul,
+                                                  double scale_x, double scale_y, const float* __restrict__ R0,
+                                                  const float* __restrict__ R1, size_t R_stride, int w, int h, int tiles_x,
+                                                  int tiles_per_img, int n_tiles, float scale, float* __restrict__ fout,
+                                                  size_t fout_stride)
+{
+    constexpr int EXT_X = FT_X + 2 * M_T;              // 76
+    constexpr int EXT_Y = FT_Y + 2 * M_T;              // 28
+    constexpr int WIN = 2 * M_T + 1;
+    constexpr int PITCH = (EXT_X + 3) & ~3;
+    constexpr int PLANE = EXT_Y * PITCH + (EXT_X - (EXT_Y * PITCH) % 64 + 128) % 64;   // = EXT_X (mod 64): float2 column pairs stay conflict-free across planes
+    constexpr int NPX = EXT_X * EXT_Y;                 // 2128
+    constexpr int NK = (NPX + 255) / 256;              // 9 region pixels per thread
+    static_assert(PLANE % 4 == 0 && EXT_X % 2 == 0, "alignment");
+    __shared__ __attribute__((aligned(16))) float ms[5 * PLANE];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int nb = gridDim.x;
+    const int per = (nb + 7) >> 3;
+    const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (tile >= n_tiles) return;
+    const int s = tile / tiles_per_img;
+    const int tr = tile - s * tiles_per_img;
+    const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+    const int x0 = tx * FT_X, y0 = ty * FT_Y;
+    const size_t npx = (size_t)w * h;
+    const float* R0p = R0 + (size_t)s * R_stride;
+    const float* R1p = R1 + (size_t)s * R_stride;
+    const float* fi = fin + (size_t)s * fin_stride;
+
+    // this thread's region pixels: i = tid + 256 k; flow-in for all of them is requested up front
+    float2 f[NK];
+#pragma unroll
+    for (int k = 0; k < NK; k++) {
+        const int i = min(tid + 256 * k, NPX - 1);
+        const int lr = i / EXT_X, lc = i - lr * EXT_X;
+        const int cx = clampi(x0 - M_T + lc, 0, w - 1), cy = clampi(y0 - M_T + lr, 0, h - 1);
+        if (MODE == 0) f[k] = make_float2(0.f, 0.f);
+        else if (MODE == 1) f[k] = upsample_flow(fi, pw, ph, mul, scale_x, scale_y, cx, cy);
+        else f[k] = *(const float2*)(fi + ((size_t)cy * w + cx) * 2);
+    }
+#pragma unroll
+    for (int k0 = 0; k0 < NK; k0 += 2) {
+        GatherPx g[2];
+        float q[2][5];
+        int cxs[2], cys[2], off[2];
+        bool val[2];
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) {
+            const int k = k0 + jj < NK ? k0 + jj : NK - 1;
+            const int iraw = tid + 256 * (k0 + jj);
+            val[jj] = (k0 + jj < NK) && iraw < NPX;
+            const int i = min(tid + 256 * k, NPX - 1);
+            const int lr = i / EXT_X, lc = i - lr * EXT_X;
+            cxs[jj] = clampi(x0 - M_T + lc, 0, w - 1);
+            cys[jj] = clampi(y0 - M_T + lr, 0, h - 1);
+            off[jj] = lr * PITCH + lc;
+            const size_t o = (size_t)cys[jj] * w + cxs[jj];
+#pragma unroll
+            for (int c = 0; c < 5; c++) q[jj][c] = R0p[c * npx + o];
+            gather_issue(R1p, npx, w, h, cxs[jj], cys[jj], f[k].x, f[k].y, g[jj]);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) {
+            const int k = k0 + jj < NK ? k0 + jj : NK - 1;
+            float o5[5];
+            update_finish(q[jj], g[jj], w, h, cxs[jj], cys[jj], f[k].x, f[k].y, o5);
+            if (val[jj]) {
+#pragma unroll
+                for (int c = 0; c < 5; c++) ms[c * PLANE + off[jj]] = o5[c];
+            }
+        }
+    }
+    __syncthreads();
+
+    {
+        constexpr int NP = EXT_X / 2;
+        for (int t = tid; t < 5 * NP; t += 256) {
+            const int c = t / NP, pr = t - c * NP;
+            float* col = ms + c * PLANE + 2 * pr;
+            float2 v[EXT_Y];
+#pragma unroll
+            for (int i = 0; i < EXT_Y; i++) v[i] = *(const float2*)(col + i * PITCH);
+            float sx = 0.f, sy = 0.f;
+#pragma unroll
+            for (int i = 0; i < WIN; i++) { sx += v[i].x; sy += v[i].y; }
+            *(float2*)col = make_float2(sx, sy);
+#pragma unroll
+            for (int y = 1; y < FT_Y; y++) {
+                sx += v[y + WIN - 1].x - v[y - 1].x;
+                sy += v[y + WIN - 1].y - v[y - 1].y;
+                *(float2*)(col + y * PITCH) = make_float2(sx, sy);
+            }
+        }
+    }
+    __syncthreads();
+
+    const int quad = (lane & 31) >> 2;
+    const int grp = (lane >> 5) * 2 + ((quad == 1 || quad == 2 || quad == 4 || quad == 7) ? 1 : 0);
+    const int qpos = (quad == 0 || quad == 1) ? 0 : ((quad == 3 || quad == 2) ? 1 : ((quad == 5 || quad == 4) ? 2 : 3));
+    const int pos = qpos * 4 + (lane & 3);
+    const int ly = wv * 4 + grp;
+    const int lx0 = pos * 4;
+    const int gx = x0 + lx0, gy = y0 + ly;
+    float S[5][4];
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        const float4* p = (const float4*)(ms + c * PLANE + ly * PITCH + lx0);
+        constexpr int NV = (4 + 2 * M_T + 3) / 4;
+        float ff[4 * NV];
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            const float4 t4 = p[k];
+            ff[4 * k] = t4.x; ff[4 * k + 1] = t4.y; ff[4 * k + 2] = t4.z; ff[4 * k + 3] = t4.w;
+        }
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < WIN; k++) a += ff[k];
+        S[c][0] = a;
+#pragma unroll
+        for (int j = 1; j < 4; j++) {
+            a += ff[j + WIN - 1] - ff[j - 1];
+            S[c][j] = a;
+        }
+    }
+    if (gx < w && gy < h) {
+        float u[4], v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            solve_px(S[0][j] * scale, S[1][j] * scale, S[2][j] * scale, S[3][j] * scale, S[4][j] * scale, &u[j], &v[j]);
+        float* fo = fout + (size_t)s * fout_stride + ((size_t)gy * w + gx) * 2;
+        *(float4*)fo = make_float4(u[0], v[0], u[1], v[1]);
+        *(float4*)(fo + 4) = make_float4(u[2], v[2], u[3], v[3]);
+    }
+}
+
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 void launch_blur_iter(hipStream_t st, const float* M_in, float* M_out, size_t M_stride, const float* R0, const float* R1,
@@ -715,4 +870,29 @@ void launch_blur_iter(hipStream_t st, const float* M_in, float* M_out, size_t M_
         hipLaunchKernelGGL(k_blur_iter_generic<0>, grid, dim3(256), lds, st, M_in, M_out, M_stride, R0, R1, R_stride, w, h, m,
                            pitch, plane, scale, do_update, flow, f_stride);
     }
+}
+
+// One recompute sweep.  mode 0: zero flow in; 1: fin = coarser layer's flow (ph x pw x 2), upsampled * mul; 2: fin = this
+// layer's flow.  Returns false when the fast form does not apply (caller falls back to the M-array kernels).
+bool launch_sweep_rc(hipStream_t st, int mode, const float* fin, size_t fin_stride, int pw, int ph, float mul, const float* R0,
+                     const float* R1, size_t R_stride, int G, int w, int h, int winsize, float* fout, size_t fout_stride)
+{
+    const bool ok = winsize / 2 == 6 && (w % 4 == 0) && (R_stride % 4 == 0) && (fout_stride % 4 == 0) && aligned16(R0) &&
+                    aligned16(R1) && aligned16(fout) && (mode == 0 || (fin && ((uintptr_t)fin & 7) == 0 && fin_stride % 2 == 0));
+    if (!ok) return false;
+    const float scale = (float)(1.0 / ((double)winsize * winsize));
+    const int tiles_x = (w + FT_X - 1) / FT_X, tiles_y = (h + FT_Y - 1) / FT_Y;
+    const int per_img = tiles_x * tiles_y, n_tiles = per_img * G;
+    const int nb = ((n_tiles + 7) / 8) * 8;
+    const double sx = pw > 0 ? (double)pw / w : 0.0, sy = ph > 0 ? (double)ph / h : 0.0;
+    if (mode == 0)
+        hipLaunchKernelGGL((k_sweep_rc<6, 0>), dim3(nb), dim3(256), 0, st, fin, fin_stride, pw, ph, mul, sx, sy, R0, R1, R_stride, w,
+                           h, tiles_x, per_img, n_tiles, scale, fout, fout_stride);
+    else if (mode == 1)
+        hipLaunchKernelGGL((k_sweep_rc<6, 1>), dim3(nb), dim3(256), 0, st, fin, fin_stride, pw, ph, mul, sx, sy, R0, R1, R_stride, w,
+                           h, tiles_x, per_img, n_tiles, scale, fout, fout_stride);
+    else
+        hipLaunchKernelGGL((k_sweep_rc<6, 2>), dim3(nb), dim3(256), 0, st, fin, fin_stride, pw, ph, mul, sx, sy, R0, R1, R_stride, w,
+                           h, tiles_x, per_img, n_tiles, scale, fout, fout_stride);
+    return true;
 }

@@ -202,6 +202,7 @@ struct ProfRec { int kid; hipEvent_t a, b; };
 
 struct mav_ctx {
     int device = 0, W = 0, H = 0, max_batch = 0, group = 0, group_fine = 1;
+    bool use_rc = false;         // option "recompute": sweeps rebuild M on the fly (k_sweep_rc) instead of storing it
     mav_fb_params fb;
     hipStream_t stream = nullptr;
     std::vector<Layer> layers;
@@ -344,6 +345,7 @@ extern "C" int mav_create(mav_ctx** out, int device, int W, int H, int max_batch
     // group: pairs per launch for everything but the finest layer's sweeps (see farneback_group).
     int group = max_batch < 8 ? max_batch : 8;
     if (const char* e = getenv("MAVFLOW_GROUP")) { int v = atoi(e); if (v >= 1) group = v < max_batch ? v : max_batch; }
+    if (const char* e = getenv("MAVFLOW_RC")) c->use_rc = atoi(e) != 0;
     if (const char* e = getenv("MAVFLOW_GROUP_FINE")) { int v = atoi(e); if (v >= 0) c->group_fine = v; }
     // the Infinity-Cache argument only holds while one pair's finest-layer working set (80 B/px) fits in it
     if ((size_t)W * H * 80 > (size_t)200 << 20) c->group_fine = 0;
@@ -372,6 +374,7 @@ extern "C" int mav_set_option(mav_ctx* c, const char* name, long value)
         HIPCHK(hipStreamSynchronize(c->stream));
         return g == c->group ? MAV_OK : alloc_group(c, g);
     }
+    if (!strcmp(name, "recompute")) { c->use_rc = value != 0; return MAV_OK; }
     if (!strcmp(name, "group_fine")) {
         if (value < 0) return fail(MAV_ERR_ARG, "group_fine must be >= 0 (0 = same as group)");
         c->group_fine = (int)value;
@@ -500,24 +503,50 @@ static int farneback_group(mav_ctx* c, const uint8_t* prev, const uint8_t* next,
             { ProfScope ps(c, K_POLYEXP);
               launch_polyexp(c->stream, c->I, n0, g, l.w, l.h, c->pc, R[i], 5 * n0); }
         }
-        { ProfScope ps(c, K_UPDATE);
-          launch_update_matrices(c->stream, c->R0, c->R1, 5 * n0, flow_prev, fc_stride, pw, ph, (float)(1. / c->fb.pyr_scale), g,
-                                 l.w, l.h, c->Ma, 5 * n0); }
         float* fdst = k > 0 ? c->fc[k & 1] : flow_out;
         const size_t fstride = k > 0 ? fc_stride : 2 * n0;
-        // The finest layer's ten sweeps re-read R0/R1 and ping-pong M: run them `group_fine` pairs at a time so that
-        // one sub-group's working set (166 MB per 1080p pair) stays resident in the 256 MB Infinity Cache between
-        // sweeps.  Coarse layers are small: all g pairs per launch to fill the 256 CUs.
+        // The finest layer's ten sweeps re-read R0/R1 (and M or the flow): run them `group_fine` pairs at a time so that
+        // one sub-group's working set stays resident in the 256 MB Infinity Cache between sweeps.  Coarse layers are
+        // small: all g pairs per launch to fill the 256 CUs.
         const int sub = (k == 0 && c->group_fine > 0 && c->group_fine < g) ? c->group_fine : g;
-        for (int s0 = 0; s0 < g; s0 += sub) {
-            const int gs = g - s0 < sub ? g - s0 : sub;
-            float *Min = c->Ma + (size_t)s0 * 5 * n0, *Mout = c->Mb + (size_t)s0 * 5 * n0;
-            for (int it = 0; it < c->fb.iterations; it++) {
-                const int upd = it < c->fb.iterations - 1;
-                { ProfScope ps(c, k == 0 ? K_ITER : K_ITER_COARSE);
-                  launch_blur_iter(c->stream, Min, Mout, 5 * n0, c->R0 + (size_t)s0 * 5 * n0, c->R1 + (size_t)s0 * 5 * n0, 5 * n0, gs,
-                                   l.w, l.h, c->fb.winsize, upd, !upd, fdst + (size_t)s0 * fstride, fstride); }
-                if (upd) { float* t = Min; Min = Mout; Mout = t; }
+        const float mul = (float)(1. / c->fb.pyr_scale);
+        // Optional form ("recompute"): sweeps that rebuild M from (R0, R1, flow) on the fly -- no M arrays, no initial-M
+        // kernel, 56 instead of 80 B/px of HBM traffic; the flow ping-pongs between the (otherwise unused) Ma / Mb buffers.
+        // On MI355X at 1080p it is slower than the M-array form (27.6 vs 21.3 ms per 64 pairs: the limit is the per-CU
+        // request rate into L2, which the 2.08x halo recomputation raises), so it is off by default.
+        bool rc_ok = c->use_rc && c->fb.winsize / 2 == 6 && l.w % 4 == 0;
+        if (rc_ok) {
+            for (int s0 = 0; s0 < g && rc_ok; s0 += sub) {
+                const int gs = g - s0 < sub ? g - s0 : sub;
+                float* buf[2] = {c->Ma + (size_t)s0 * 5 * n0, c->Mb + (size_t)s0 * 5 * n0};
+                for (int it = 0; it < c->fb.iterations; it++) {
+                    const bool last = it == c->fb.iterations - 1;
+                    const int mode = it > 0 ? 2 : (flow_prev ? 1 : 0);
+                    const float* fin = it > 0 ? buf[(it - 1) & 1] : (flow_prev ? flow_prev + (size_t)s0 * fc_stride : nullptr);
+                    const size_t fin_stride = it > 0 ? 5 * n0 : fc_stride;
+                    float* fo = last ? fdst + (size_t)s0 * fstride : buf[it & 1];
+                    ProfScope ps(c, k == 0 ? K_ITER : K_ITER_COARSE);
+                    if (!launch_sweep_rc(c->stream, mode, fin, fin_stride, pw, ph, mul, c->R0 + (size_t)s0 * 5 * n0,
+                                         c->R1 + (size_t)s0 * 5 * n0, 5 * n0, gs, l.w, l.h, c->fb.winsize, fo, last ? fstride : 5 * n0)) {
+                        rc_ok = false;      // (only possible on the very first launch: alignment) -> M-array form below
+                        break;
+                    }
+                }
+            }
+        }
+        if (!rc_ok) {
+            { ProfScope ps(c, K_UPDATE);
+              launch_update_matrices(c->stream, c->R0, c->R1, 5 * n0, flow_prev, fc_stride, pw, ph, mul, g, l.w, l.h, c->Ma, 5 * n0); }
+            for (int s0 = 0; s0 < g; s0 += sub) {
+                const int gs = g - s0 < sub ? g - s0 : sub;
+                float *Min = c->Ma + (size_t)s0 * 5 * n0, *Mout = c->Mb + (size_t)s0 * 5 * n0;
+                for (int it = 0; it < c->fb.iterations; it++) {
+                    const int upd = it < c->fb.iterations - 1;
+                    { ProfScope ps(c, k == 0 ? K_ITER : K_ITER_COARSE);
+                      launch_blur_iter(c->stream, Min, Mout, 5 * n0, c->R0 + (size_t)s0 * 5 * n0, c->R1 + (size_t)s0 * 5 * n0, 5 * n0, gs,
+                                       l.w, l.h, c->fb.winsize, upd, !upd, fdst + (size_t)s0 * fstride, fstride); }
+                    if (upd) { float* t = Min; Min = Mout; Mout = t; }
+                }
             }
         }
         flow_prev = fdst; pw = l.w; ph = l.h;

@@ -47,6 +47,8 @@ void launch_blur_iter(hipStream_t st, const float* M_in, float* M_out, size_t M_
                       size_t R_stride, int G, int w, int h, int winsize, int do_update, int store_flow, float* flow, size_t f_stride);
 // store_flow == 0: the sweep's flow is consumed inside the kernel only (valid when do_update != 0)
 size_t blur_iter_lds_bytes(int winsize);
+bool launch_sweep_rc(hipStream_t st, int mode, const float* fin, size_t fin_stride, int pw, int ph, float mul, const float* R0,
+                     const float* R1, size_t R_stride, int G, int w, int h, int winsize, float* fout, size_t fout_stride);
 
 // ---- detection kernels (kernels_detect.hip, compiled with -ffp-contract=off) --------------------------------
 struct FoeScratch {

@@ -168,3 +168,30 @@ def test_shape_errors(ctx640):
         ctx640.farneback(np.zeros((480, 641), np.uint8), np.zeros((480, 641), np.uint8))
     with pytest.raises(ValueError):
         ctx640.farneback(np.zeros((5, 480, 640), np.uint8), np.zeros((5, 480, 640), np.uint8))   # batch > max_batch
+
+
+def test_recompute_sweeps_give_the_same_flow(mav, fb_oracle):
+    """Option "recompute" (M rebuilt inside every sweep instead of stored): the same algebra with differently contracted
+    f32 operations -- equal to rounding noise, and inside the oracle tolerance on its own."""
+    from mavflow import _lib
+    prev, nxt = synth.make_batch(640, 480, 2, distinct=2)
+    with _lib.Context(640, 480, 2) as c:
+        a = c.farneback(prev, nxt)
+        c.set_option("recompute", 1)
+        b = c.farneback(prev, nxt)
+    assert np.abs(a - b).max() < 1e-3, np.abs(a - b).max()
+    _check_flow(b[1], fb_oracle.calc(prev[1], nxt[1]), "recompute")
+
+
+def test_flow_4k_five_layers(mav, fb_oracle):
+    """BASELINE config 5 shape: 3840x2160, levels=5 (blur kernels of 95/37/13/5/3 taps), one pair."""
+    from mavflow import _lib
+    from oracle import fb_oracle as fbo
+    W, H = 3840, 2160
+    f0, f1, _ = synth.make_pair(W, H, 7, k=0.004)
+    fb = _lib.fb_defaults(levels=5)
+    with _lib.Context(W, H, 1, fb) as c:
+        assert c.num_layers() == 5 and [c.layer_dims(k)[3] for k in range(5)] == [3, 5, 13, 37, 95]
+        got = c.farneback(f0, f1)[0]
+    e = _check_flow(got, fb_oracle.calc(f0, f1, fbo.default_params(levels=5)), "4K / 5 layers")
+    print(f"\nEPE vs oracle 4K: mean {e.mean():.3e} p99.9 {np.percentile(e, 99.9):.3e}")
