@@ -167,8 +167,15 @@ def main():
         iters = ctx.fb.iterations
         bytes_step = B * sum(w * h * ((iters - 1) * ITER_BYTES_UPDATE + ITER_BYTES_LAST) for (w, h) in layers)
         achieved = bytes_step / (ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "k_blur_iter", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        # HBM bytes from the PMC counters (collected by tools/pmc_passes.sh in separate rocprofv3 --pmc runs, corrected as the
+        # microarchitecture guide prescribes, committed under profiles/): per launch, like `achieved`.  null when not measured
+        # for this workload shape.
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "r01", "traffic.json")
+        if os.path.exists(tj) and (W, H) == (1920, 1080) and ctx.fb.iterations == 10 and len(layers) == 2:
+            traffic = int(json.load(open(tj))["hbm_bytes_per_pair"] * B / max(launches, 1))
+        roofline = {"bound": "hbm", "kernel": "k_blur_iter_fast (all sweep launches of a step)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "avg_launch_ms": round(ms / max(launches, 1), 4), "launches_per_step": launches,
                     "alg_bytes_per_launch_avg": int(bytes_step / max(launches, 1)),
                     "kernel_share_of_step": round(ms / (1e3 * elapsed / args.steps), 3),
