@@ -250,7 +250,55 @@ static __device__ __forceinline__ double phi_exact(double u, double v, double d2
     return acos(arg) * (180.0 / 3.141592653589793238462643383279502884);
 }
 
-template <typename FlowT>
+// One pixel of the phi / mask stage: screen in f32, exact double path inside the guard bands (or when phi is wanted).
+static __device__ __forceinline__ void phi_pixel(double u, double v, int x, int y, double foex, double foey, bool notsky,
+                                                 const mav_thr_params& thr, const PhiScreen& scr, bool* fix_out, bool* dyn_out,
+                                                 double* ph_out, bool* have_ph)
+{
+    const double d2x = (double)x - foex, d2y = (double)y - foey;
+    *have_ph = false;
+    if (scr.enabled) {
+        // Single-precision screen.  phi > T  <=>  arg < cos(T)  (arccos is monotone), and every f32 quantity below is within
+        // 1e-6 (absolute, in arg units) / 1e-6 (relative, magnitudes) of its double counterpart, so a decision taken outside
+        // the guard bands is the decision the exact path would take.  Pixels inside a band (a ~1e-4 fraction) fall through.
+        const float uf = (float)u, vf = (float)v, dxf = (float)d2x, dyf = (float)d2y;
+        const float m2 = uf * uf + vf * vf, dd = dxf * dxf + dyf * dyf;
+        const float prod2 = m2 * dd;
+        const float arg = (uf * dxf + vf * dyf) * rsqrtf(prod2);
+        bool sure = prod2 > 1e-8f && prod2 < 1e30f;       // norm floor (1e-6) and inf/NaN stay on the exact path
+        const bool gate_f = m2 > scr.fmm2, gate_d = m2 > scr.dmm2;
+        sure = sure && fabsf(m2 - scr.fmm2) > 1e-5f * scr.fmm2 && fabsf(m2 - scr.dmm2) > 1e-5f * scr.dmm2;
+        bool f = false, d = false;
+        if (gate_f && notsky) {
+            sure = sure && fabsf(arg - scr.cos_fixed) > 2e-5f;
+            f = arg < scr.cos_fixed;
+        }
+        if (gate_d && notsky) {
+            const float T = scr.dyn_ab + scr.dyn_c * rsqrtf(m2);  // degrees
+            if (T < 179.f) {
+                const float cT = __cosf(T * 0.017453292519943295f);
+                sure = sure && fabsf(arg - cT) > 1e-4f;
+                d = arg < cT;
+            } else
+                sure = sure && T > 181.f;                         // phi <= 180 < T: certainly false
+        }
+        if (sure) { *fix_out = f; *dyn_out = d; return; }
+    }
+    double fm;
+    const double ph = phi_exact(u, v, d2x, d2y, &fm);
+    const double t = thr.dyn_b + thr.dyn_c / fm;
+    const bool hi = ph > (thr.dyn_a + t);
+    const bool lo = ph < (thr.dyn_a - t);
+    *dyn_out = (fm > thr.dyn_min_mag) && notsky && (lo || hi);
+    const double gated = ((fm > thr.fixed_min_mag) && notsky) ? ph : 0.0;
+    *fix_out = gated > thr.fixed_deg;
+    *ph_out = ph;
+    *have_ph = true;
+}
+
+// VEC = 4: one thread = 4 consecutive pixels x 4 rows (W % 4 == 0): float4 / double2 row loads, uchar4 mask stores;
+// workgroup = 256 columns x 16 rows.  VEC = 1: any width, one pixel per lane and row, 4 rows per thread.
+template <typename FlowT, int VEC>
 __global__ __launch_bounds__(256) void k_phi_mask(const FlowT* __restrict__ flow, const DerotParams* __restrict__ derot,
                                                   const double* __restrict__ foe, const uint8_t* __restrict__ sky, int W, int H,
                                                   mav_thr_params thr, PhiScreen scr, double* __restrict__ phi_out,
@@ -258,69 +306,46 @@ __global__ __launch_bounds__(256) void k_phi_mask(const FlowT* __restrict__ flow
                                                   int32_t* __restrict__ box_acc, unsigned long long* __restrict__ max_phi_bits)
 {
     const int b = blockIdx.z;
-    const int lane = threadIdx.x & 63;
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const size_t npx = (size_t)W * H;
     const FlowT* fl = flow + b * npx * 2;
     const DerotParams* dp = derot ? derot + b : nullptr;
     const double foex = foe[2 * b], foey = foe[2 * b + 1];
     int bx0 = INT_MAX, by0 = INT_MAX, bx1 = -1, by1 = -1;
     double pmax = 0.0;
-    if (y < H) {
+    const int xb = (blockIdx.x * 64 + lane) * VEC;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int x = blockIdx.x * 256 + j * 64 + lane;
-            if (x >= W) continue;
+    for (int r = 0; r < 4; r++) {
+        const int y = blockIdx.y * 16 + wv * 4 + r;
+        if (y >= H || xb >= W) continue;
+        const size_t o = b * npx + (size_t)y * W + xb;
+        uint8_t sk[VEC], mf[VEC], md[VEC];
+        if (VEC == 4) {
+            const uint32_t s4 = sky ? *(const uint32_t*)(sky + o) : 0u;
+            sk[0] = s4 & 255u; sk[1 % VEC] = (s4 >> 8) & 255u; sk[2 % VEC] = (s4 >> 16) & 255u; sk[3 % VEC] = s4 >> 24;
+        } else
+            sk[0] = sky ? sky[o] : 0;
+#pragma unroll
+        for (int j = 0; j < VEC; j++) {
+            const int x = xb + j;
             double u, v;
             flow_at(fl, dp, W, H, y, x, &u, &v);
-            const double d2x = (double)x - foex, d2y = (double)y - foey;
-            const size_t o = b * npx + (size_t)y * W + x;
-            const bool notsky = sky ? (sky[o] == 0) : true;
-            bool fix, dyn;
-            bool decided = false;
-            if (scr.enabled) {
-                // Single-precision screen.  phi > T  <=>  arg < cos(T)  (arccos is monotone), and every f32 quantity below
-                // is within 1e-6 (absolute, in arg units) / 1e-6 (relative, magnitudes) of its double counterpart, so a
-                // decision taken outside the guard bands is the decision the exact path would take.  Pixels inside a band
-                // (a ~1e-4 fraction) fall through to the exact path.
-                const float uf = (float)u, vf = (float)v, dxf = (float)d2x, dyf = (float)d2y;
-                const float m2 = uf * uf + vf * vf, dd = dxf * dxf + dyf * dyf;
-                const float prod2 = m2 * dd;
-                const float arg = (uf * dxf + vf * dyf) * rsqrtf(prod2);
-                bool sure = prod2 > 1e-8f && prod2 < 1e30f;       // norm floor (1e-6) and inf/NaN stay on the exact path
-                const bool gate_f = m2 > scr.fmm2, gate_d = m2 > scr.dmm2;
-                sure = sure && fabsf(m2 - scr.fmm2) > 1e-5f * scr.fmm2 && fabsf(m2 - scr.dmm2) > 1e-5f * scr.dmm2;
-                bool f = false, d = false;
-                if (gate_f && notsky) {
-                    sure = sure && fabsf(arg - scr.cos_fixed) > 2e-5f;
-                    f = arg < scr.cos_fixed;
-                }
-                if (gate_d && notsky) {
-                    const float T = scr.dyn_ab + scr.dyn_c * rsqrtf(m2);  // degrees
-                    if (T < 179.f) {
-                        const float cT = __cosf(T * 0.017453292519943295f);
-                        sure = sure && fabsf(arg - cT) > 1e-4f;
-                        d = arg < cT;
-                    } else
-                        sure = sure && T > 181.f;                         // phi <= 180 < T: certainly false
-                }
-                if (sure) { fix = f; dyn = d; decided = true; }
-            }
-            if (!decided) {
-                double fm;
-                const double ph = phi_exact(u, v, d2x, d2y, &fm);
-                const double t = thr.dyn_b + thr.dyn_c / fm;
-                const bool hi = ph > (thr.dyn_a + t);
-                const bool lo = ph < (thr.dyn_a - t);
-                dyn = (fm > thr.dyn_min_mag) && notsky && (lo || hi);
-                const double gated = ((fm > thr.fixed_min_mag) && notsky) ? ph : 0.0;
-                fix = gated > thr.fixed_deg;
-                if (phi_out) phi_out[o] = ph;
+            bool fix, dyn, have;
+            double ph = 0.0;
+            phi_pixel(u, v, x, y, foex, foey, sk[j] == 0, thr, scr, &fix, &dyn, &ph, &have);
+            if (have) {
+                if (phi_out) phi_out[o + j] = ph;
                 pmax = ph > pmax ? ph : pmax;
             }
-            if (mfix) mfix[o] = fix ? 1 : 0;
-            if (mdyn) mdyn[o] = dyn ? 1 : 0;
+            mf[j] = fix ? 1 : 0; md[j] = dyn ? 1 : 0;
             if (fix) { bx0 = min(bx0, x); bx1 = max(bx1, x); by0 = min(by0, y); by1 = max(by1, y); }
+        }
+        if (VEC == 4) {
+            if (mfix) *(uint32_t*)(mfix + o) = mf[0] | (mf[1 % VEC] << 8) | (mf[2 % VEC] << 16) | ((uint32_t)mf[3 % VEC] << 24);
+            if (mdyn) *(uint32_t*)(mdyn + o) = md[0] | (md[1 % VEC] << 8) | (md[2 % VEC] << 16) | ((uint32_t)md[3 % VEC] << 24);
+        } else {
+            if (mfix) mfix[o] = mf[0];
+            if (mdyn) mdyn[o] = md[0];
         }
     }
     wave_box_commit(bx0, by0, bx1, by1, box_acc + 4 * b);
@@ -352,21 +377,34 @@ static PhiScreen phi_screen(const mav_thr_params& t, const double* phi, const un
     return s;
 }
 
+template <typename FlowT>
+static void launch_phi_mask_t(hipStream_t st, const FlowT* flow, const DerotParams* derot, const double* foe, const uint8_t* sky,
+                              int B, int W, int H, mav_thr_params thr, double* phi, uint8_t* mask_fixed, uint8_t* mask_dyn,
+                              int32_t* box_acc, unsigned long long* max_phi_bits)
+{
+    const PhiScreen scr = phi_screen(thr, phi, max_phi_bits);
+    const bool vec = W % 4 == 0 && (((uintptr_t)sky | (uintptr_t)mask_fixed | (uintptr_t)mask_dyn) & 3) == 0;
+    if (vec) {
+        dim3 grid((W / 4 + 63) / 64, (H + 15) / 16, B);
+        hipLaunchKernelGGL((k_phi_mask<FlowT, 4>), grid, dim3(256), 0, st, flow, derot, foe, sky, W, H, thr, scr, phi, mask_fixed,
+                           mask_dyn, box_acc, max_phi_bits);
+    } else {
+        dim3 grid((W + 63) / 64, (H + 15) / 16, B);
+        hipLaunchKernelGGL((k_phi_mask<FlowT, 1>), grid, dim3(256), 0, st, flow, derot, foe, sky, W, H, thr, scr, phi, mask_fixed,
+                           mask_dyn, box_acc, max_phi_bits);
+    }
+}
 void launch_phi_mask_f32(hipStream_t st, const float* flow, const DerotParams* derot, const double* foe, const uint8_t* sky,
                          int B, int W, int H, mav_thr_params thr, double* phi, uint8_t* mask_fixed, uint8_t* mask_dyn,
                          int32_t* box_acc, unsigned long long* max_phi_bits)
 {
-    dim3 grid((W + 255) / 256, (H + 3) / 4, B);
-    hipLaunchKernelGGL(k_phi_mask<float>, grid, dim3(256), 0, st, flow, derot, foe, sky, W, H, thr,
-                       phi_screen(thr, phi, max_phi_bits), phi, mask_fixed, mask_dyn, box_acc, max_phi_bits);
+    launch_phi_mask_t<float>(st, flow, derot, foe, sky, B, W, H, thr, phi, mask_fixed, mask_dyn, box_acc, max_phi_bits);
 }
 void launch_phi_mask_f64(hipStream_t st, const double* flow, const double* foe, const uint8_t* sky, int B, int W, int H,
                          mav_thr_params thr, double* phi, uint8_t* mask_fixed, uint8_t* mask_dyn, int32_t* box_acc,
                          unsigned long long* max_phi_bits)
 {
-    dim3 grid((W + 255) / 256, (H + 3) / 4, B);
-    hipLaunchKernelGGL(k_phi_mask<double>, grid, dim3(256), 0, st, flow, (const DerotParams*)nullptr, foe, sky, W, H, thr,
-                       phi_screen(thr, phi, max_phi_bits), phi, mask_fixed, mask_dyn, box_acc, max_phi_bits);
+    launch_phi_mask_t<double>(st, flow, nullptr, foe, sky, B, W, H, thr, phi, mask_fixed, mask_dyn, box_acc, max_phi_bits);
 }
 
 __global__ void k_finalize(const int32_t* __restrict__ box_acc, const double* __restrict__ foe, int B, mav_result* __restrict__ res,
