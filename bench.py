@@ -119,8 +119,9 @@ def main():
     def step():
         run_batch()
         if dist is not None:
-            ctx.sync()
+            ctx.sync()                                   # records are complete before the collective reads them
             mdist.allgather_records(dist, t_local, t_all)
+            torch.cuda.synchronize()                     # ... and gathered before the next step overwrites them
 
     def barrier():
         ctx.sync()
