@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="pairs per GPU per step")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--levels", type=int, default=1, help="Farneback levels (BASELINE config 5 uses 5 at 3840x2160)")
     ap.add_argument("--group", type=int, default=0, help="pairs per launch (0 = library default)")
     ap.add_argument("--group-fine", type=int, default=-1, help="pairs per launch for the finest layer's sweeps (-1 = library default)")
     ap.add_argument("--cpu-pairs", type=int, default=3, help="pairs in the CPU baseline sample (0 = skip)")
@@ -85,7 +86,7 @@ def main():
     from mavflow import _lib, synth
 
     W, H, B = args.width, args.height, args.batch
-    ctx = _lib.Context(W, H, B, device=local_rank)
+    ctx = _lib.Context(W, H, B, _lib.fb_defaults(levels=args.levels), device=local_rank)
     if args.group:
         ctx.set_option("group", args.group)
     if args.group_fine >= 0:

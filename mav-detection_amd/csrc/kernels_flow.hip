@@ -15,46 +15,50 @@ static __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v <
 
 // ------------------------------------------------------------------------------------------------------------
 // Layer image: convertTo(f32) -> GaussianBlur(ksize, sigma, REFLECT_101) -> resize(INTER_LINEAR), fused through
-// the host-built 1-D tap tables (A.2).  One thread per output pixel; u8 source rows are re-read through L1/L2.
+// the host-built 1-D tap tables (A.2).
 // ------------------------------------------------------------------------------------------------------------
-template <int TAPS_T>   // > 0: tap tables of one output pixel live in registers; 0: runtime tap count
-__global__ __launch_bounds__(256) void k_blur_resize(const uint8_t* __restrict__ img, size_t img_stride, int W, int H,
-                                                     int w, int h, ResizeTables t, float* __restrict__ out,
-                                                     size_t out_stride)
+// Two separable passes for the coarse layers (any ksize / scale).  Tables are stored TRANSPOSED ([tap][output index]) so a
+// wave's 64 consecutive outputs read 64 consecutive table entries per tap.
+//   pass H   tmp[y][dx] = sum_tx xw[tx][dx] * src[y][xi[tx][dx]]        for every source row y          (H x w f32)
+//   pass V   out[dy][dx] = sum_ty yw[ty][dy] * tmp[yi[ty][dy]][dx]                                     (h x w f32)
+// MACs per output drop from (ksize+1)^2 to ~(ksize+1)(H/h + 1): 95-tap layers of the 4K / 5-layer preset cost the same as
+// the 5-tap one.
+template <int TAPS_T>   // > 0: compile-time tap count (all table and pixel loads of a thread in flight together)
+__global__ __launch_bounds__(256) void k_blur_resize_h(const uint8_t* __restrict__ img, size_t img_stride, int W, int H, int w,
+                                                       ResizeTables t, float* __restrict__ tmp, size_t tmp_stride)
+{
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 4;       // 4 source rows per thread share the column taps
+    if (dx >= w || y0 >= H) return;
+    const uint8_t* base = img + (size_t)blockIdx.z * img_stride;
+    float* dst = tmp + (size_t)blockIdx.z * tmp_stride + dx;
+    const int taps = TAPS_T > 0 ? TAPS_T : t.taps;
+    float r[4] = {0.f, 0.f, 0.f, 0.f};
+    const uint8_t* rows[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) rows[k] = base + (size_t)min(y0 + k, H - 1) * W;
+#pragma unroll(TAPS_T > 0 ? TAPS_T : 4)
+    for (int tx = 0; tx < taps; tx++) {
+        const int xi = t.xi[(size_t)tx * w + dx];
+        const float xw = t.xw[(size_t)tx * w + dx];
+#pragma unroll
+        for (int k = 0; k < 4; k++) r[k] += xw * (float)rows[k][xi];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (y0 + k < H) dst[(size_t)(y0 + k) * w] = r[k];
+}
+__global__ __launch_bounds__(256) void k_blur_resize_v(const float* __restrict__ tmp, size_t tmp_stride, int w, int h,
+                                                       ResizeTables t, float* __restrict__ out, size_t out_stride)
 {
     const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
     const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (dx >= w || dy >= h) return;
-    const int taps = TAPS_T > 0 ? TAPS_T : t.taps;
-    const uint8_t* src = img + (size_t)blockIdx.z * img_stride;
-    const int* xi = t.xi + (size_t)dx * taps;
-    const float* xw = t.xw + (size_t)dx * taps;
-    const int* yi = t.yi + (size_t)dy * taps;
-    const float* yw = t.yw + (size_t)dy * taps;
+    const float* src = tmp + (size_t)blockIdx.z * tmp_stride + dx;
     float acc = 0.f;
-    if (TAPS_T > 0) {
-        int cx[TAPS_T > 0 ? TAPS_T : 1];
-        float cw[TAPS_T > 0 ? TAPS_T : 1];
-#pragma unroll
-        for (int tx = 0; tx < TAPS_T; tx++) { cx[tx] = xi[tx]; cw[tx] = xw[tx]; }
-#pragma unroll
-        for (int ty = 0; ty < TAPS_T; ty++) {
-            const float wy = yw[ty];
-            const uint8_t* row = src + (size_t)yi[ty] * W;
-            float r = 0.f;
-#pragma unroll
-            for (int tx = 0; tx < TAPS_T; tx++) r += cw[tx] * (float)row[cx[tx]];
-            acc += wy * r;
-        }
-    } else {
-        for (int ty = 0; ty < taps; ty++) {
-            const float wy = yw[ty];
-            if (wy == 0.f) continue;
-            const uint8_t* row = src + (size_t)yi[ty] * W;
-            float r = 0.f;
-            for (int tx = 0; tx < taps; tx++) r += xw[tx] * (float)row[xi[tx]];
-            acc += wy * r;
-        }
+    for (int ty = 0; ty < t.taps; ty++) {
+        const float wy = t.yw[(size_t)ty * h + dy];
+        if (wy != 0.f) acc += wy * src[(size_t)t.yi[(size_t)ty * h + dy] * w];
     }
     out[(size_t)blockIdx.z * out_stride + (size_t)dy * w + dx] = acc;
 }
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(256) void k_blur3_u8(const uint8_t* __restrict__ im
 }
 
 void launch_blur_resize(hipStream_t st, const uint8_t* img, size_t img_stride, int G, int W, int H, int w, int h,
-                        ResizeTables t, float* out, size_t out_stride)
+                        ResizeTables t, float* tmp, size_t tmp_stride, float* out, size_t out_stride)
 {
     if (w == W && h == H && t.taps == 4 && t.fixed3 && W % 4 == 0 && W >= 8 && H >= 2 && img_stride % 4 == 0 &&
         out_stride % 4 == 0 && ((uintptr_t)img & 3) == 0 && ((uintptr_t)out & 15) == 0) {
@@ -108,13 +112,13 @@ void launch_blur_resize(hipStream_t st, const uint8_t* img, size_t img_stride, i
         hipLaunchKernelGGL(k_blur3_u8, grid, dim3(256), 0, st, img, img_stride, W, H, out, out_stride);
         return;
     }
-    dim3 grid((w + 63) / 64, (h + 3) / 4, G);
+    const dim3 gh((w + 63) / 64, ((H + 3) / 4 + 3) / 4, G);
     if (t.taps == 6)
-        hipLaunchKernelGGL(k_blur_resize<6>, grid, dim3(256), 0, st, img, img_stride, W, H, w, h, t, out, out_stride);
-    else if (t.taps == 4)
-        hipLaunchKernelGGL(k_blur_resize<4>, grid, dim3(256), 0, st, img, img_stride, W, H, w, h, t, out, out_stride);
+        hipLaunchKernelGGL(k_blur_resize_h<6>, gh, dim3(256), 0, st, img, img_stride, W, H, w, t, tmp, tmp_stride);
     else
-        hipLaunchKernelGGL(k_blur_resize<0>, grid, dim3(256), 0, st, img, img_stride, W, H, w, h, t, out, out_stride);
+        hipLaunchKernelGGL(k_blur_resize_h<0>, gh, dim3(256), 0, st, img, img_stride, W, H, w, t, tmp, tmp_stride);
+    hipLaunchKernelGGL(k_blur_resize_v, dim3((w + 63) / 64, (h + 3) / 4, G), dim3(256), 0, st, (const float*)tmp, tmp_stride, w, h,
+                       t, out, out_stride);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -114,8 +114,8 @@ static void build_axis_table(int S, int d, int ksize, const std::vector<float>& 
             float wgt = 0.f;
             if (t < ksize) wgt += a0 * g[t];
             if (t >= 1) wgt += a1 * g[t - 1];
-            idx[(size_t)o * taps + t] = reflect101(col, S);
-            wt[(size_t)o * taps + t] = wgt;
+            idx[(size_t)t * d + o] = reflect101(col, S);     // transposed: [tap][output]
+            wt[(size_t)t * d + o] = wgt;
         }
     }
 }
@@ -209,6 +209,8 @@ struct mav_ctx {
     PolyCoef pc;
     // workspace (group slots)
     size_t n0 = 0, n1 = 0;
+    float *Htmp = nullptr;           // scratch of the separable blur+resize: group x H x (widest coarse layer)
+    size_t htmp_stride = 0;
     float *I = nullptr, *R0 = nullptr, *R1 = nullptr, *Ma = nullptr, *Mb = nullptr, *fc[2] = {nullptr, nullptr};
     float* flow_ws = nullptr;      // lazily allocated (max_batch) when the caller does not want the flow
     // detection scratch (max_batch)
@@ -246,7 +248,7 @@ static void free_layer(Layer& l)
 
 static int alloc_group(mav_ctx* c, int group)
 {
-    float** bufs[] = {&c->I, &c->R0, &c->R1, &c->Ma, &c->Mb, &c->fc[0], &c->fc[1]};
+    float** bufs[] = {&c->I, &c->R0, &c->R1, &c->Ma, &c->Mb, &c->fc[0], &c->fc[1], &c->Htmp};
     for (auto b : bufs) { if (*b) hipFree(*b); *b = nullptr; }
     c->group = group;
     const size_t g = (size_t)group;
@@ -257,6 +259,7 @@ static int alloc_group(mav_ctx* c, int group)
     HIPCHK(hipMalloc(&c->Mb, sizeof(float) * 5 * c->n0 * g));
     HIPCHK(hipMalloc(&c->fc[0], sizeof(float) * 2 * (c->n1 ? c->n1 : 1) * g));
     HIPCHK(hipMalloc(&c->fc[1], sizeof(float) * 2 * (c->n1 ? c->n1 : 1) * g));
+    HIPCHK(hipMalloc(&c->Htmp, sizeof(float) * c->htmp_stride * g));
     return MAV_OK;
 }
 
@@ -266,7 +269,7 @@ extern "C" int mav_destroy(mav_ctx* c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto& l : c->layers) free_layer(l);
-    void* bufs[] = {c->I, c->R0, c->R1, c->Ma, c->Mb, c->fc[0], c->fc[1], c->flow_ws, c->foe_sc.cand, c->foe_sc.count,
+    void* bufs[] = {c->I, c->R0, c->R1, c->Ma, c->Mb, c->fc[0], c->fc[1], c->Htmp, c->flow_ws, c->foe_sc.cand, c->foe_sc.count,
                     c->foe_sc.best_key, c->foe_dev, c->box_acc, c->u64_scratch, c->i32_scratch, c->derot_dev};
     for (void* b : bufs) if (b) hipFree(b);
     for (auto& r : c->prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
@@ -342,6 +345,7 @@ extern "C" int mav_create(mav_ctx** out, int device, int W, int H, int max_batch
     }
     c->n0 = (size_t)W * H;
     c->n1 = levels >= 1 ? (size_t)c->layers[1].w * c->layers[1].h : 0;
+    c->htmp_stride = (size_t)H * W;                    // any layer (even layer 0 when its fast form does not apply) fits
     // group: pairs per launch for everything but the finest layer's sweeps (see farneback_group).
     int group = max_batch < 8 ? max_batch : 8;
     if (const char* e = getenv("MAVFLOW_GROUP")) { int v = atoi(e); if (v >= 1) group = v < max_batch ? v : max_batch; }
@@ -499,7 +503,7 @@ static int farneback_group(mav_ctx* c, const uint8_t* prev, const uint8_t* next,
         float* R[2] = {c->R0, c->R1};
         for (int i = 0; i < 2; i++) {
             { ProfScope ps(c, K_BLUR_RESIZE);
-              launch_blur_resize(c->stream, img[i], n0, g, c->W, c->H, l.w, l.h, tables_of(l), c->I, n0); }
+              launch_blur_resize(c->stream, img[i], n0, g, c->W, c->H, l.w, l.h, tables_of(l), c->Htmp, c->htmp_stride, c->I, n0); }
             { ProfScope ps(c, K_POLYEXP);
               launch_polyexp(c->stream, c->I, n0, g, l.w, l.h, c->pc, R[i], 5 * n0); }
         }
@@ -845,7 +849,8 @@ extern "C" int mav_stage_blur_resize(mav_ctx* c, const uint8_t* img, int k, floa
     const size_t n = (size_t)l->w * l->h;
     DevBuf di, dout;
     CHK(di.upload(c, img, c->n0)); CHK(dout.alloc(n * sizeof(float)));
-    launch_blur_resize(c->stream, di.as<uint8_t>(), c->n0, 1, c->W, c->H, l->w, l->h, tables_of(*l), dout.as<float>(), n);
+    launch_blur_resize(c->stream, di.as<uint8_t>(), c->n0, 1, c->W, c->H, l->w, l->h, tables_of(*l), c->Htmp, c->htmp_stride,
+                       dout.as<float>(), n);
     CHK(check_launch("blur_resize"));
     CHK(download(c, out, dout.p, n * sizeof(float)));
     return mav_sync(c);
