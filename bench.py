@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--levels", type=int, default=1, help="Farneback levels (BASELINE config 5 uses 5 at 3840x2160)")
     ap.add_argument("--group", type=int, default=0, help="pairs per launch (0 = library default)")
     ap.add_argument("--group-fine", type=int, default=-1, help="pairs per launch for the finest layer's sweeps (-1 = library default)")
-    ap.add_argument("--cpu-pairs", type=int, default=3, help="pairs in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-pairs", type=int, default=16, help="pairs in the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
 

@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256) void k_blur_iter_fast(const float* __restrict_
                                                         size_t M_stride, const float* __restrict__ R0,
                                                         const float* __restrict__ R1, size_t R_stride, int w, int h,
                                                         int tiles_x, int tiles_per_img, int n_tiles, float scale,
-                                                        int do_update, int store_flow, float* __restrict__ flow, size_t f_stride, int dbg)
+                                                        int do_update, int store_flow, float* __restrict__ flow, size_t f_stride)
 {
     constexpr int EXT_X = FT_X + 2 * M_T;              // 76
     constexpr int EXT_Y = FT_Y + 2 * M_T;              // 28
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(256) void k_blur_iter_fast(const float* __restrict_
             float2 v[EXT_Y];
 #pragma unroll
             for (int i = 0; i < EXT_Y; i++)
-                v[i] = (dbg & 1) ? make_float2((float)i, (float)pr) : *(const float2*)(col + (size_t)clampi(y0 - M_T + i, 0, h - 1) * w);
+                v[i] = *(const float2*)(col + (size_t)clampi(y0 - M_T + i, 0, h - 1) * w);
             float* out = vs + c * PLANE + 2 * pr;
             float sx = 0.f, sy = 0.f;
 #pragma unroll
@@ -660,7 +660,6 @@ __global__ __launch_bounds__(256) void k_blur_iter_fast(const float* __restrict_
         *(float4*)(vs + ly * PITCH + lx0) = make_float4(u[0], u[1], u[2], u[3]);
         *(float4*)(vs + PLANE + ly * PITCH + lx0) = make_float4(v[0], v[1], v[2], v[3]);
     }
-    if (dbg & 2) return;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -676,14 +675,13 @@ __global__ __launch_bounds__(256) void k_blur_iter_fast(const float* __restrict_
             const int ly = wv * 4 + jb + jj;
             fu[jj] = vs[ly * PITCH + lane];
             fv[jj] = vs[PLANE + ly * PITCH + lane];
-            if (dbg & 4) fu[jj] = 1e9f;
             gather_issue(R1p, npx, w, h, gxc, gys[jb + jj], fu[jj], fv[jj], g[jj]);
         }
 #pragma unroll
         for (int jj = 0; jj < 2; jj++) {
             float o[5];
             update_finish(q[jb + jj], g[jj], w, h, gxc, gys[jb + jj], fu[jj], fv[jj], o);
-            if (colok && y0 + wv * 4 + jb + jj < h && !(dbg & 8)) {
+            if (colok && y0 + wv * 4 + jb + jj < h) {
                 const size_t idx = (size_t)gys[jb + jj] * w + gxc;
 #pragma unroll
                 for (int c = 0; c < 5; c++) Mo[c * npx + idx] = o[c];
@@ -851,13 +849,12 @@ void launch_blur_iter(hipStream_t st, const float* M_in, float* M_out, size_t M_
     dim3 grid((w + MAV_TILE - 1) / MAV_TILE, (h + MAV_TILE - 1) / MAV_TILE, G);
     const bool vec_ok = (w % 4 == 0) && (M_stride % 4 == 0) && (R_stride % 4 == 0) && (f_stride % 4 == 0) && aligned16(M_in) &&
                         aligned16(M_out) && aligned16(R0) && aligned16(R1) && aligned16(flow);
-    static const int dbg = getenv("MAVFLOW_DBG") ? atoi(getenv("MAVFLOW_DBG")) : 0;   // ablation switches (diagnostics only)
     if (m == 6 && vec_ok) {
         const int tiles_x = (w + FT_X - 1) / FT_X, tiles_y = (h + FT_Y - 1) / FT_Y;
         const int per_img = tiles_x * tiles_y, n_tiles = per_img * G;
         const int nb = ((n_tiles + 7) / 8) * 8;        // the XCD-aware renumbering needs a multiple of 8 workgroups
         hipLaunchKernelGGL(k_blur_iter_fast<6>, dim3(nb), dim3(256), 0, st, M_in, M_out, M_stride, R0, R1, R_stride, w, h,
-                           tiles_x, per_img, n_tiles, scale, do_update, store_flow, flow, f_stride, dbg);
+                           tiles_x, per_img, n_tiles, scale, do_update, store_flow, flow, f_stride);
         return;
     }
     iter_geometry(m, &ext, &pitch, &plane);
