@@ -88,6 +88,11 @@ int mav_derotate(mav_ctx*, const float* flow, const double* omega, const double*
 /* FocusOfExpansion.get_FOE_dense + ransac [src/focus_of_expansion.py:32-86]; samples (batch, 2N, 2) = (row, col)
  * drawn by the caller exactly as :70-71 does (the GPU never generates them). foe (batch, 2). */
 int mav_foe_dense(mav_ctx*, const double* flow, const uint32_t* samples, int batch, const mav_foe_params*, double* foe);
+/* FocusOfExpansion.ransac [src/focus_of_expansion.py:32-54] on caller-supplied estimates (count, 2), count <= 4096:
+ * first estimate with the strictly largest number of others within ransac_threshold; (0, 0) when none has a neighbour. */
+int mav_ransac(mav_ctx*, const double* estimates, int count, double ransac_threshold, double* foe /* 2 */);
+/* cv2.cvtColor(img, COLOR_BGR2GRAY) [src/farneback.py:21,74] for (batch, H, W, 3) u8 frames -> (batch, H, W) u8. */
+int mav_bgr2gray(mav_ctx*, const uint8_t* bgr, int batch, uint8_t* gray);
 /* FocusOfExpansion.get_phi [src/focus_of_expansion.py:150-184] + threshold block [src/processor.py:333-341].
  * sky: (batch,H,W) u8 or NULL; phi (degrees), mask_fixed, mask_dyn, max_phi (batch) are each optional (NULL). */
 int mav_phi_mask(mav_ctx*, const double* flow, const double* foe, const uint8_t* sky, int batch, const mav_thr_params*,

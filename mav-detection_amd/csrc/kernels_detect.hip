@@ -548,3 +548,30 @@ void launch_tpr_fpr(hipStream_t st, const uint8_t* gt, const uint8_t* mask, int 
     hipMemsetAsync(counts, 0, sizeof(unsigned long long) * 4 * B, st);
     hipLaunchKernelGGL(k_tpr_fpr, dim3(128, B), dim3(256), 0, st, gt, mask, (size_t)W * H, counts);
 }
+
+// cv2.cvtColor(COLOR_BGR2GRAY) on u8 (farneback.py:21,74): fixed point, (B*1868 + G*9617 + R*4899 + 8192) >> 14  (SURVEY A.7).
+__global__ __launch_bounds__(256) void k_bgr2gray(const uint8_t* __restrict__ bgr, size_t n, uint8_t* __restrict__ gray)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const uint8_t* p = bgr + 3 * i;
+        gray[i] = (uint8_t)((p[0] * 1868u + p[1] * 9617u + p[2] * 4899u + 8192u) >> 14);
+    }
+}
+void launch_bgr2gray(hipStream_t st, const uint8_t* bgr, size_t n, uint8_t* gray)
+{
+    const size_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(k_bgr2gray, dim3((unsigned)(blocks < 4096 ? (blocks ? blocks : 1) : 4096)), dim3(256), 0, st, bgr, n, gray);
+}
+
+// FocusOfExpansion.ransac on caller-supplied estimates (already in s.cand[0..M), s.count[0] = M): vote + pick.
+__global__ void k_set_count(FoeScratch sc, int M)
+{
+    sc.count[0] = M;
+    sc.best_key[0] = 0ull;
+}
+void launch_ransac_only(hipStream_t st, FoeScratch s, int M, int N, double dist2_thr, double* foe)
+{
+    hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, st, s, M);
+    if (M > 0) hipLaunchKernelGGL(k_ransac, dim3((M + 255) / 256, 1), dim3(256), sizeof(double2) * (size_t)N, st, s, N, dist2_thr);
+    hipLaunchKernelGGL(k_foe_finalize, dim3(1), dim3(64), 0, st, s, N, 1, foe);
+}

@@ -776,6 +776,33 @@ extern "C" int mav_bbox(mav_ctx* c, const uint8_t* img, int batch, int32_t* box)
     return mav_sync(c);
 }
 
+extern "C" int mav_bgr2gray(mav_ctx* c, const uint8_t* bgr, int batch, uint8_t* gray)
+{
+    CHK(check_batch(c, batch, "mav_bgr2gray"));
+    if (!bgr || !gray) return fail(MAV_ERR_ARG, "mav_bgr2gray: NULL argument");
+    const size_t n = c->n0 * batch;
+    DevBuf di, dg;
+    CHK(di.upload(c, bgr, 3 * n)); CHK(dg.alloc(n));
+    launch_bgr2gray(c->stream, di.as<uint8_t>(), n, dg.as<uint8_t>());
+    CHK(check_launch("bgr2gray"));
+    CHK(download(c, gray, dg.p, n));
+    return mav_sync(c);
+}
+
+extern "C" int mav_ransac(mav_ctx* c, const double* estimates, int count, double ransac_threshold, double* foe)
+{
+    if (!c || !foe || (count > 0 && !estimates)) return fail(MAV_ERR_ARG, "mav_ransac: NULL argument");
+    if (count < 0 || count > 4096) return fail(MAV_ERR_ARG, "mav_ransac: count %d outside [0, 4096]", count);
+    HIPCHK(hipSetDevice(c->device));
+    const int N = count > 0 ? count : 1;
+    CHK(ensure_foe_scratch(c, N));
+    if (count > 0) HIPCHK(hipMemcpyAsync(c->foe_sc.cand, estimates, sizeof(double) * 2 * count, hipMemcpyHostToDevice, c->stream));
+    launch_ransac_only(c->stream, c->foe_sc, count, c->foe_sc_n, sq_threshold(ransac_threshold), c->foe_dev);
+    CHK(check_launch("ransac"));
+    CHK(download(c, foe, c->foe_dev, sizeof(double) * 2));
+    return mav_sync(c);
+}
+
 extern "C" int mav_window_max(mav_ctx* c, const uint8_t* img, int batch, int64_t* out)
 {
     CHK(check_batch(c, batch, "mav_window_max"));

@@ -78,3 +78,5 @@ void launch_window_max(hipStream_t st, const uint8_t* img, int B, int W, int H, 
                        int64_t* out);
 void launch_tpr_fpr(hipStream_t st, const uint8_t* gt, const uint8_t* mask, int B, int W, int H,
                     unsigned long long* counts /*[B][4]*/);
+void launch_bgr2gray(hipStream_t st, const uint8_t* bgr, size_t n, uint8_t* gray);
+void launch_ransac_only(hipStream_t st, FoeScratch s, int M, int N, double dist2_thr, double* foe);

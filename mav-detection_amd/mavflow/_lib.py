@@ -42,7 +42,7 @@ assert RESULT_DTYPE.itemsize == C.sizeof(Result) == 32
 EXPORTS = [
     "mav_fb_defaults", "mav_foe_defaults", "mav_thr_defaults", "mav_create", "mav_destroy", "mav_last_error",
     "mav_device_count", "mav_set_option", "mav_num_layers", "mav_layer_dims", "mav_farneback", "mav_derotate",
-    "mav_foe_dense", "mav_phi_mask", "mav_bbox", "mav_window_max", "mav_tpr_fpr_counts", "mav_process_batch",
+    "mav_foe_dense", "mav_ransac", "mav_bgr2gray", "mav_phi_mask", "mav_bbox", "mav_window_max", "mav_tpr_fpr_counts", "mav_process_batch",
     "mav_farneback_dev", "mav_process_batch_dev", "mav_sync", "mav_stream", "mav_dev_alloc", "mav_dev_free",
     "mav_memcpy_h2d", "mav_memcpy_d2h", "mav_timer_start", "mav_timer_stop", "mav_profile_enable", "mav_profile_get",
     "mav_comm_unique_id", "mav_comm_init", "mav_comm_destroy", "mav_allgather_results", "mav_stage_blur_resize",
@@ -76,6 +76,8 @@ def load() -> C.CDLL:
     lib.mav_farneback_dev.argtypes = [vp, vp, vp, C.c_int, vp]
     lib.mav_derotate.argtypes = [vp, vp, vp, vp, C.c_int, vp]
     lib.mav_foe_dense.argtypes = [vp, vp, vp, C.c_int, C.POINTER(FoeParams), vp]
+    lib.mav_ransac.argtypes = [vp, vp, C.c_int, C.c_double, vp]
+    lib.mav_bgr2gray.argtypes = [vp, vp, C.c_int, vp]
     lib.mav_phi_mask.argtypes = [vp, vp, vp, vp, C.c_int, C.POINTER(ThrParams), vp, vp, vp, vp]
     lib.mav_bbox.argtypes = [vp, vp, C.c_int, vp]
     lib.mav_window_max.argtypes = [vp, vp, C.c_int, vp]
@@ -264,6 +266,20 @@ class Context:
         foe = np.empty((B, 2), np.float64)
         check(self.lib.mav_foe_dense(self.h, _ptr(flow), _ptr(samples), B, C.byref(p), _ptr(foe)))
         return foe
+
+    def ransac(self, estimates, ransac_threshold: float = 30.0):
+        est = _arr(np.asarray(estimates, np.float64).reshape(-1, 2), np.float64)
+        foe = np.empty(2, np.float64)
+        check(self.lib.mav_ransac(self.h, _ptr(est) if est.shape[0] else None, est.shape[0], float(ransac_threshold), _ptr(foe)))
+        return (float(foe[0]), float(foe[1]))
+
+    def bgr2gray(self, bgr) -> np.ndarray:
+        a = np.asarray(bgr)
+        a = a[None] if a.ndim == 3 else a
+        a = _arr(a, np.uint8, (a.shape[0], self.H, self.W, 3), "bgr")
+        gray = np.empty((a.shape[0], self.H, self.W), np.uint8)
+        check(self.lib.mav_bgr2gray(self.h, _ptr(a), a.shape[0], _ptr(gray)))
+        return gray
 
     def phi_mask(self, flow, foe, sky=None, params: ThrParams | None = None, want_phi=True):
         flow = np.asarray(flow, np.float64)

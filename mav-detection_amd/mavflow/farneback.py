@@ -12,7 +12,8 @@ from . import _lib
 
 
 def bgr_to_gray(img: np.ndarray) -> np.ndarray:
-    """cv2.cvtColor(COLOR_BGR2GRAY) on u8: fixed-point (B*1868 + G*9617 + R*4899 + 8192) >> 14."""
+    """cv2.cvtColor(COLOR_BGR2GRAY) on u8: fixed-point (B*1868 + G*9617 + R*4899 + 8192) >> 14.
+    Host form of the formula (used by tests as the checker of mav_bgr2gray); the class below converts on the GPU."""
     a = np.asarray(img)
     if a.ndim == 2:
         return np.ascontiguousarray(a, np.uint8)
@@ -41,19 +42,22 @@ class Farneback:
         self.capture = capture
         self.output = output
         _, prev = self.capture.read()
-        self.prevgray = bgr_to_gray(prev)
-        H, W = self.prevgray.shape
+        H, W = prev.shape[:2]
         fb = _lib.fb_defaults()
         for k, v in self.PARAMS.items():
             setattr(fb, k, v)
         self.ctx = _lib.Context(W, H, 1, fb)
+        self.prevgray = self._gray(prev)
         self.flow = np.zeros((H, W, 2), np.float32)
         self.history_length = 1
         self.prev_result = np.zeros((H, W, 3), np.uint8)
 
+    def _gray(self, img: np.ndarray) -> np.ndarray:
+        return self.ctx.bgr2gray(img)[0] if img.ndim == 3 else np.ascontiguousarray(img, np.uint8)
+
     def process(self) -> np.ndarray:
         _, img = self.capture.read()
-        gray = bgr_to_gray(img)
+        gray = self._gray(img)
         self.flow = self.ctx.farneback(self.prevgray, gray)[0]
         self.prevgray = gray
         result = flow_to_bgr(self.flow)

@@ -42,6 +42,10 @@ class FocusOfExpansion:
         p.ransac_threshold = float(self.ransac_threshold)
         return p
 
+    def ransac(self, estimates: np.ndarray) -> Tuple[float, float]:
+        """First estimate with the strictly largest number of others within ransac_threshold; (0.0, 0.0) if none has any."""
+        return im_helpers._ctx(self.flow_width, self.flow_height).ransac(estimates, self.ransac_threshold)
+
     def get_FOE_dense(self, flow_uv: np.ndarray) -> Tuple[float, float]:
         """FoE from N = 1000 random flow-line intersections + the RANSAC vote.  float32 input is promoted to double
         (the reference's frame-0 path gates |flow| in float32; the two agree unless |flow2| is within 1e-7 of 2.5)."""

@@ -207,3 +207,24 @@ def test_process_batch_equals_staged_calls(mav):
         np.testing.assert_allclose(out["phi"][b], ref["phi"], rtol=0, atol=PHI_ATOL)
         assert np.array_equal(out["mask_fixed"][b], ref["fixed"]) and np.array_equal(out["mask_dyn"][b], ref["total"])
         assert tuple(out["results"][b]["box"]) == tuple(ref["box"])
+
+
+def test_ransac_entry_point_golden(ctx_small, golden):
+    for tag in ("iso", "tie", "clus"):
+        got = ctx_small.ransac(golden[f"ransac_{tag}_in"])
+        assert got == tuple(golden[f"ransac_{tag}_out"]), tag
+    assert ctx_small.ransac(np.zeros((0, 2))) == (0.0, 0.0) == tuple(golden["ransac_empty_out"])
+    rng = np.random.default_rng(4)
+    est = np.concatenate([rng.normal(200, 10, (700, 2)), rng.uniform(-500, 900, (300, 2))])
+    assert ctx_small.ransac(est) == fo.ransac(est)
+    assert ctx_small.ransac(est, 5.0) == fo.ransac(est, 5.0)
+
+
+def test_bgr2gray(ctx_small):
+    from mavflow.farneback import bgr_to_gray
+    rng = np.random.default_rng(2)
+    bgr = rng.integers(0, 256, (2, 120, 160, 3)).astype(np.uint8)
+    bgr[0, 0, :5] = [[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255], [10, 20, 30]]
+    got = ctx_small.bgr2gray(bgr)
+    assert np.array_equal(got, np.stack([bgr_to_gray(b) for b in bgr]))
+    assert got[0, 0, :5].tolist() == [29, 150, 76, 255, 22]
