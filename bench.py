@@ -38,18 +38,29 @@ def b_alg_per_pair(layers, W, H, iters):
 
 
 def cpu_baseline(prev, nxt, samples, n_sample):
-    """The oracle (C restatement of Farneback + numpy FoE chain) on a bounded sample of the same workload, 1 core."""
+    """The CPU path on a bounded sample of the same workload, timed on this node's host cores (1 thread).
+    Preferred: cv2.calcOpticalFlowFarneback (kind "reference") when OpenCV is importable on the node; otherwise the oracle's C
+    restatement (kind "port", labelled as such).  The numpy FoE chain follows either."""
     import numpy as np
-    from oracle import fb_oracle, foe_oracle
-    orc = fb_oracle.load()
+    from oracle import foe_oracle
+    try:
+        import cv2
+        cv2.setNumThreads(1)
+        flow_fn = lambda a, b: cv2.calcOpticalFlowFarneback(a, b, None, 0.4, 1, 12, 10, 8, 1.2, 0)
+        kind, label = "reference", f"cv2 {cv2.__version__} calcOpticalFlowFarneback (1 thread)"
+    except ImportError:
+        from oracle import fb_oracle
+        orc = fb_oracle.load()
+        flow_fn = orc.calc
+        kind, label = "port", "oracle/farneback_oracle.c (restatement, not OpenCV: cv2 is not importable on this node)"
     t0 = time.perf_counter()
     for b in range(n_sample):
-        flow = orc.calc(prev[b], nxt[b])
+        flow = flow_fn(prev[b], nxt[b])
         foe_oracle.run_chain(flow, samples[b])
     dt = time.perf_counter() - t0
-    return {"value": n_sample / dt, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
-            "sample": f"{n_sample} of the benchmark's 1920x1080 pairs, oracle/farneback_oracle.c (restatement, not OpenCV: "
-                      f"cv2 is absent) + numpy FoE chain, {dt:.1f} s, host has {os.cpu_count()} cores"}
+    return {"value": n_sample / dt, "unit": "frame-pairs/s", "cores": 1, "kind": kind,
+            "sample": f"{n_sample} of the benchmark's {prev.shape[2]}x{prev.shape[1]} pairs, {label} + numpy FoE chain, {dt:.1f} s, "
+                      f"host has {os.cpu_count()} cores"}
 
 
 def main():
