@@ -110,3 +110,13 @@ def test_bad_arguments(fb_oracle):
     p.pyr_scale = 1.0
     with pytest.raises(ValueError):
         fb_oracle.calc(a, a, p)
+
+
+def test_oracle_vs_cv2_when_available(fb_oracle):
+    """Pins the restatement wherever OpenCV exists (it does not in the build image: skipped, parity unpinned)."""
+    cv2 = pytest.importorskip("cv2")
+    f0, f1, _ = synth.make_pair(640, 480, 0)
+    ref = cv2.calcOpticalFlowFarneback(f0, f1, None, 0.4, 1, 12, 10, 8, 1.2, 0)
+    got = fb_oracle.calc(f0, f1)
+    e = np.hypot(got[..., 0] - ref[..., 0], got[..., 1] - ref[..., 1])
+    assert e.mean() <= 1e-3 and e.max() <= 1e-1, (e.mean(), e.max())
