@@ -14,53 +14,106 @@
 static __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // ------------------------------------------------------------------------------------------------------------
-// Layer image: convertTo(f32) -> GaussianBlur(ksize, sigma, REFLECT_101) -> resize(INTER_LINEAR), fused through
-// the host-built 1-D tap tables (A.2).
+// Layer image: convertTo(f32) -> GaussianBlur(ksize, sigma, REFLECT_101) -> resize(INTER_LINEAR)   (A.2).
 // ------------------------------------------------------------------------------------------------------------
-// Two separable passes for the coarse layers (any ksize / scale).  Tables are stored TRANSPOSED ([tap][output index]) so a
-// wave's 64 consecutive outputs read 64 consecutive table entries per tap.
-//   pass H   tmp[y][dx] = sum_tx xw[tx][dx] * src[y][xi[tx][dx]]        for every source row y          (H x w f32)
-//   pass V   out[dy][dx] = sum_ty yw[ty][dy] * tmp[yi[ty][dy]][dx]                                     (h x w f32)
-// MACs per output drop from (ksize+1)^2 to ~(ksize+1)(H/h + 1): 95-tap layers of the 4K / 5-layer preset cost the same as
+// Two separable passes for the coarse layers (any ksize / scale), table-free: along each axis the output is
+//   a0 * B[s0] + a1 * B[s0 + 1],   B[c] = sum_t g[t] * src[reflect101(c - r + t)]
+// with (s0, a1) from the half-pixel-centre rule of resize(INTER_LINEAR).  Away from the border the two Gaussian sums share
+// their pixels (B[s0+1] is B[s0] shifted by one), so a tap costs one load and two FMAs; g[t] is wave-uniform (scalar loads).
+//   pass H   tmp[y][dx]   for every source row y            (H x w f32; 4 rows per thread share the column arithmetic)
+//   pass V   out[dy][dx]  from tmp                          (h x w f32)
+// MACs per output drop from (ksize+1)^2 to ~(ksize+1)(H/h + 1): the 95-tap layer of the 4K / 5-layer preset costs the same as
 // the 5-tap one.
-template <int TAPS_T>   // > 0: compile-time tap count (all table and pixel loads of a thread in flight together)
+static __device__ __forceinline__ void resize_coord(int o, int S, int d, double scale, int* s0, float* f)
+{
+    if (d == S) { *s0 = o; *f = 0.f; return; }
+    float t = (float)((o + 0.5) * scale - 0.5);
+    int s = (int)floorf(t);
+    t -= s;
+    if (s < 0) { t = 0.f; s = 0; }
+    if (s >= S - 1) { t = 0.f; s = S - 1; }
+    *s0 = s; *f = t;
+}
+static __device__ __forceinline__ int reflect101d(int p, int len)
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
+    return p;
+}
+
 __global__ __launch_bounds__(256) void k_blur_resize_h(const uint8_t* __restrict__ img, size_t img_stride, int W, int H, int w,
-                                                       ResizeTables t, float* __restrict__ tmp, size_t tmp_stride)
+                                                       BlurParams bp, float* __restrict__ tmp, size_t tmp_stride)
 {
     const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 4;       // 4 source rows per thread share the column taps
+    const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 4;
     if (dx >= w || y0 >= H) return;
     const uint8_t* base = img + (size_t)blockIdx.z * img_stride;
-    float* dst = tmp + (size_t)blockIdx.z * tmp_stride + dx;
-    const int taps = TAPS_T > 0 ? TAPS_T : t.taps;
-    float r[4] = {0.f, 0.f, 0.f, 0.f};
+    int s0; float f;
+    resize_coord(dx, W, w, bp.scale_x, &s0, &f);
+    const int r = bp.ksize >> 1;
+    const int s1 = s0 + 1 < W ? s0 + 1 : s0;
     const uint8_t* rows[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) rows[k] = base + (size_t)min(y0 + k, H - 1) * W;
-#pragma unroll(TAPS_T > 0 ? TAPS_T : 4)
-    for (int tx = 0; tx < taps; tx++) {
-        const int xi = t.xi[(size_t)tx * w + dx];
-        const float xw = t.xw[(size_t)tx * w + dx];
+    float b0[4] = {0.f, 0.f, 0.f, 0.f}, b1[4] = {0.f, 0.f, 0.f, 0.f};
+    if (s0 - r >= 0 && s0 + 1 + r < W) {               // interior: B[s0+1] re-uses B[s0]'s pixels shifted by one
+        float prev[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) r[k] += xw * (float)rows[k][xi];
+        for (int k = 0; k < 4; k++) prev[k] = (float)rows[k][s0 - r];
+        for (int t = 0; t < bp.ksize; t++) {
+            const float g = bp.g[t];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float nxt = (float)rows[k][s0 - r + t + 1];
+                b0[k] += g * prev[k];
+                b1[k] += g * nxt;
+                prev[k] = nxt;
+            }
+        }
+    } else {
+        for (int t = 0; t < bp.ksize; t++) {
+            const float g = bp.g[t];
+            const int c0 = reflect101d(s0 - r + t, W), c1 = reflect101d(s1 - r + t, W);
+#pragma unroll
+            for (int k = 0; k < 4; k++) { b0[k] += g * (float)rows[k][c0]; b1[k] += g * (float)rows[k][c1]; }
+        }
     }
+    float* dst = tmp + (size_t)blockIdx.z * tmp_stride + dx;
+    const float a0 = 1.f - f;
 #pragma unroll
     for (int k = 0; k < 4; k++)
-        if (y0 + k < H) dst[(size_t)(y0 + k) * w] = r[k];
+        if (y0 + k < H) dst[(size_t)(y0 + k) * w] = b0[k] * a0 + b1[k] * f;
 }
-__global__ __launch_bounds__(256) void k_blur_resize_v(const float* __restrict__ tmp, size_t tmp_stride, int w, int h,
-                                                       ResizeTables t, float* __restrict__ out, size_t out_stride)
+
+__global__ __launch_bounds__(256) void k_blur_resize_v(const float* __restrict__ tmp, size_t tmp_stride, int H, int w, int h,
+                                                       BlurParams bp, float* __restrict__ out, size_t out_stride)
 {
     const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
     const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (dx >= w || dy >= h) return;
     const float* src = tmp + (size_t)blockIdx.z * tmp_stride + dx;
-    float acc = 0.f;
-    for (int ty = 0; ty < t.taps; ty++) {
-        const float wy = t.yw[(size_t)ty * h + dy];
-        if (wy != 0.f) acc += wy * src[(size_t)t.yi[(size_t)ty * h + dy] * w];
+    int s0; float f;
+    resize_coord(dy, H, h, bp.scale_y, &s0, &f);
+    const int r = bp.ksize >> 1;
+    const int s1 = s0 + 1 < H ? s0 + 1 : s0;
+    float b0 = 0.f, b1 = 0.f;
+    if (s0 - r >= 0 && s0 + 1 + r < H) {
+        float prev = src[(size_t)(s0 - r) * w];
+        for (int t = 0; t < bp.ksize; t++) {
+            const float g = bp.g[t];
+            const float nxt = src[(size_t)(s0 - r + t + 1) * w];
+            b0 += g * prev;
+            b1 += g * nxt;
+            prev = nxt;
+        }
+    } else {
+        for (int t = 0; t < bp.ksize; t++) {
+            const float g = bp.g[t];
+            b0 += g * src[(size_t)reflect101d(s0 - r + t, H) * w];
+            b1 += g * src[(size_t)reflect101d(s1 - r + t, H) * w];
+        }
     }
-    out[(size_t)blockIdx.z * out_stride + (size_t)dy * w + dx] = acc;
+    out[(size_t)blockIdx.z * out_stride + (size_t)dy * w + dx] = b0 * (1.f - f) + b1 * f;
 }
 
 // Layer 0 (scale 1, sigma 0 -> fixed kernel [1/4, 1/2, 1/4], BORDER_REFLECT_101): every product is exact in f32,
@@ -104,21 +157,18 @@ __global__ __launch_bounds__(256) void k_blur3_u8(const uint8_t* __restrict__ im
 }
 
 void launch_blur_resize(hipStream_t st, const uint8_t* img, size_t img_stride, int G, int W, int H, int w, int h,
-                        ResizeTables t, float* tmp, size_t tmp_stride, float* out, size_t out_stride)
+                        BlurParams bp, float* tmp, size_t tmp_stride, float* out, size_t out_stride)
 {
-    if (w == W && h == H && t.taps == 4 && t.fixed3 && W % 4 == 0 && W >= 8 && H >= 2 && img_stride % 4 == 0 &&
-        out_stride % 4 == 0 && ((uintptr_t)img & 3) == 0 && ((uintptr_t)out & 15) == 0) {
+    if (w == W && h == H && bp.fixed3 && W % 4 == 0 && W >= 8 && H >= 2 && img_stride % 4 == 0 && out_stride % 4 == 0 &&
+        ((uintptr_t)img & 3) == 0 && ((uintptr_t)out & 15) == 0) {
         dim3 grid((W / 4 + 63) / 64, ((H + 3) / 4 + 3) / 4, G);
         hipLaunchKernelGGL(k_blur3_u8, grid, dim3(256), 0, st, img, img_stride, W, H, out, out_stride);
         return;
     }
-    const dim3 gh((w + 63) / 64, ((H + 3) / 4 + 3) / 4, G);
-    if (t.taps == 6)
-        hipLaunchKernelGGL(k_blur_resize_h<6>, gh, dim3(256), 0, st, img, img_stride, W, H, w, t, tmp, tmp_stride);
-    else
-        hipLaunchKernelGGL(k_blur_resize_h<0>, gh, dim3(256), 0, st, img, img_stride, W, H, w, t, tmp, tmp_stride);
-    hipLaunchKernelGGL(k_blur_resize_v, dim3((w + 63) / 64, (h + 3) / 4, G), dim3(256), 0, st, (const float*)tmp, tmp_stride, w, h,
-                       t, out, out_stride);
+    hipLaunchKernelGGL(k_blur_resize_h, dim3((w + 63) / 64, ((H + 3) / 4 + 3) / 4, G), dim3(256), 0, st, img, img_stride, W, H, w, bp,
+                       tmp, tmp_stride);
+    hipLaunchKernelGGL(k_blur_resize_v, dim3((w + 63) / 64, (h + 3) / 4, G), dim3(256), 0, st, (const float*)tmp, tmp_stride, H, w, h,
+                       bp, out, out_stride);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -90,36 +90,6 @@ static void gaussian_kernel(int n, double sigma, std::vector<float>& k)  // getG
     for (int i = 0; i < n; i++) k[i] = (float)(k[i] * sum);
 }
 
-// 1-D tap table of "Gaussian blur (REFLECT_101) then linear resize (half-pixel centres, clamped)" along one axis.
-static void build_axis_table(int S, int d, int ksize, const std::vector<float>& g, std::vector<int>& idx, std::vector<float>& wt)
-{
-    const int taps = ksize + 1, r = ksize / 2;
-    idx.assign((size_t)d * taps, 0);
-    wt.assign((size_t)d * taps, 0.f);
-    const double scale = (double)S / d;
-    for (int o = 0; o < d; o++) {
-        int s0;
-        float f;
-        if (d == S) { s0 = o; f = 0.f; }
-        else {
-            f = (float)((o + 0.5) * scale - 0.5);
-            s0 = (int)floorf(f);
-            f -= s0;
-            if (s0 < 0) { f = 0.f; s0 = 0; }
-            if (s0 >= S - 1) { f = 0.f; s0 = S - 1; }
-        }
-        const float a0 = 1.f - f, a1 = f;
-        for (int t = 0; t < taps; t++) {
-            const int col = s0 - r + t;  // tap t of B[s0] and tap t-1 of B[s0+1] read the same source column
-            float wgt = 0.f;
-            if (t < ksize) wgt += a0 * g[t];
-            if (t >= 1) wgt += a1 * g[t - 1];
-            idx[(size_t)t * d + o] = reflect101(col, S);     // transposed: [tap][output]
-            wt[(size_t)t * d + o] = wgt;
-        }
-    }
-}
-
 static bool inv6_cholesky(const double G[36], double inv[36])
 {
     double L[36];
@@ -191,8 +161,7 @@ static bool prepare_poly(int n, double sigma, PolyCoef* pc)  // FarnebackPrepare
 struct Layer {
     int w, h, ksize;
     double sigma;
-    int *xi = nullptr, *yi = nullptr;
-    float *xw = nullptr, *yw = nullptr;
+    float* g = nullptr;      // device copy of the Gaussian taps (getGaussianKernel(ksize, sigma, CV_32F))
 };
 
 enum KernelId { K_BLUR_RESIZE, K_POLYEXP, K_UPDATE, K_ITER, K_ITER_COARSE, K_FOE, K_PHI, K_MISC, K_COUNT };
@@ -242,8 +211,8 @@ struct ProfScope {
 
 static void free_layer(Layer& l)
 {
-    if (l.xi) hipFree(l.xi); if (l.yi) hipFree(l.yi); if (l.xw) hipFree(l.xw); if (l.yw) hipFree(l.yw);
-    l.xi = l.yi = nullptr; l.xw = l.yw = nullptr;
+    if (l.g) hipFree(l.g);
+    l.g = nullptr;
 }
 
 static int alloc_group(mav_ctx* c, int group)
@@ -330,18 +299,8 @@ extern "C" int mav_create(mav_ctx** out, int device, int W, int H, int max_batch
         if (l.w < 1 || l.h < 1) { fail(MAV_ERR_ARG, "layer %d collapses to %dx%d", k, l.w, l.h); return bail(MAV_ERR_ARG); }
         std::vector<float> g;
         gaussian_kernel(l.ksize, l.sigma, g);
-        std::vector<int> xi, yi;
-        std::vector<float> xw, yw;
-        build_axis_table(W, l.w, l.ksize, g, xi, xw);
-        build_axis_table(H, l.h, l.ksize, g, yi, yw);
-        HIPB(hipMalloc(&l.xi, xi.size() * sizeof(int)));
-        HIPB(hipMalloc(&l.xw, xw.size() * sizeof(float)));
-        HIPB(hipMalloc(&l.yi, yi.size() * sizeof(int)));
-        HIPB(hipMalloc(&l.yw, yw.size() * sizeof(float)));
-        HIPB(hipMemcpy(l.xi, xi.data(), xi.size() * sizeof(int), hipMemcpyHostToDevice));
-        HIPB(hipMemcpy(l.xw, xw.data(), xw.size() * sizeof(float), hipMemcpyHostToDevice));
-        HIPB(hipMemcpy(l.yi, yi.data(), yi.size() * sizeof(int), hipMemcpyHostToDevice));
-        HIPB(hipMemcpy(l.yw, yw.data(), yw.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIPB(hipMalloc(&l.g, g.size() * sizeof(float)));
+        HIPB(hipMemcpy(l.g, g.data(), g.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     c->n0 = (size_t)W * H;
     c->n1 = levels >= 1 ? (size_t)c->layers[1].w * c->layers[1].h : 0;
@@ -488,7 +447,10 @@ static int check_launch(const char* what)
 }
 
 // ---- Farneback pipeline ----------------------------------------------------------------------------------
-static ResizeTables tables_of(const Layer& l) { return ResizeTables{l.ksize + 1, (l.ksize == 3 && l.sigma <= 0) ? 1 : 0, l.xi, l.xw, l.yi, l.yw}; }
+static BlurParams blur_of(const mav_ctx* c, const Layer& l)
+{
+    return BlurParams{l.ksize, (l.ksize == 3 && l.sigma <= 0) ? 1 : 0, l.g, (double)c->W / l.w, (double)c->H / l.h};
+}
 
 static int farneback_group(mav_ctx* c, const uint8_t* prev, const uint8_t* next, int g, float* flow_out)
 {
@@ -503,7 +465,7 @@ static int farneback_group(mav_ctx* c, const uint8_t* prev, const uint8_t* next,
         float* R[2] = {c->R0, c->R1};
         for (int i = 0; i < 2; i++) {
             { ProfScope ps(c, K_BLUR_RESIZE);
-              launch_blur_resize(c->stream, img[i], n0, g, c->W, c->H, l.w, l.h, tables_of(l), c->Htmp, c->htmp_stride, c->I, n0); }
+              launch_blur_resize(c->stream, img[i], n0, g, c->W, c->H, l.w, l.h, blur_of(c, l), c->Htmp, c->htmp_stride, c->I, n0); }
             { ProfScope ps(c, K_POLYEXP);
               launch_polyexp(c->stream, c->I, n0, g, l.w, l.h, c->pc, R[i], 5 * n0); }
         }
@@ -876,7 +838,7 @@ extern "C" int mav_stage_blur_resize(mav_ctx* c, const uint8_t* img, int k, floa
     const size_t n = (size_t)l->w * l->h;
     DevBuf di, dout;
     CHK(di.upload(c, img, c->n0)); CHK(dout.alloc(n * sizeof(float)));
-    launch_blur_resize(c->stream, di.as<uint8_t>(), c->n0, 1, c->W, c->H, l->w, l->h, tables_of(*l), c->Htmp, c->htmp_stride,
+    launch_blur_resize(c->stream, di.as<uint8_t>(), c->n0, 1, c->W, c->H, l->w, l->h, blur_of(c, *l), c->Htmp, c->htmp_stride,
                        dout.as<float>(), n);
     CHK(check_launch("blur_resize"));
     CHK(download(c, out, dout.p, n * sizeof(float)));

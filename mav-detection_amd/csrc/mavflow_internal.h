@@ -16,14 +16,14 @@ struct PolyCoef {
     float ig11, ig03, ig33, ig55;
 };
 
-// Fused GaussianBlur + resize(INTER_LINEAR) as two 1-D tap tables: out(dx,dy) = sum_ty yw[ty][dy] * sum_tx xw[tx][dx] * src[yi[ty][dy]][xi[tx][dx]]
-struct ResizeTables {
-    int taps;          // ksize + 1
-    int fixed3;        // ksize == 3 with the fixed kernel [1/4, 1/2, 1/4] (sigma == 0) and no resampling
-    const int* xi;     // [taps][w]  (transposed: consecutive outputs are consecutive in memory)
-    const float* xw;   // [taps][w]
-    const int* yi;     // [taps][h]
-    const float* yw;   // [taps][h]
+// GaussianBlur(ksize, sigma) + resize(INTER_LINEAR) of one layer: the f32 Gaussian taps (device memory, getGaussianKernel) and
+// the two resize ratios; everything else is arithmetic inside the kernels.
+struct BlurParams {
+    int ksize;
+    int fixed3;          // ksize == 3 with the fixed kernel [1/4, 1/2, 1/4] (sigma == 0)
+    const float* g;      // [ksize]
+    double scale_x;      // W / w
+    double scale_y;      // H / h
 };
 
 struct DerotParams {  // one pair; Detector.derotate
@@ -34,7 +34,7 @@ struct DerotParams {  // one pair; Detector.derotate
 // ---- flow kernels (kernels_flow.hip) ----------------------------------------------------------------------
 // All take G slots; slot s reads/writes base + s*stride (strides in elements).
 void launch_blur_resize(hipStream_t st, const uint8_t* img, size_t img_stride, int G, int W, int H, int w, int h,
-                        ResizeTables t, float* tmp /* G x H x w scratch for the separable passes */, size_t tmp_stride, float* out,
+                        BlurParams bp, float* tmp /* G x H x w scratch for the separable passes */, size_t tmp_stride, float* out,
                         size_t out_stride);
 void launch_polyexp(hipStream_t st, const float* I, size_t I_stride, int G, int w, int h, const PolyCoef& pc, float* R,
                     size_t R_stride);
