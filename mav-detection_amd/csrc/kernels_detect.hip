@@ -575,3 +575,22 @@ void launch_ransac_only(hipStream_t st, FoeScratch s, int M, int N, double dist2
     if (M > 0) hipLaunchKernelGGL(k_ransac, dim3((M + 255) / 256, 1), dim3(256), sizeof(double2) * (size_t)N, st, s, N, dist2_thr);
     hipLaunchKernelGGL(k_foe_finalize, dim3(1), dim3(64), 0, st, s, N, 1, foe);
 }
+
+// DerotParams from device-resident omega (B,3) and dt (B, nullable = 1): sx = w*dt/2, sy = h*dt/2 (detector.py:101-102).
+__global__ void k_make_derot(const double* __restrict__ omega, const double* __restrict__ dt, int B, int W, int H,
+                             DerotParams* __restrict__ out)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double d = dt ? dt[b] : 1.0;
+    DerotParams p;
+    p.o0 = omega[3 * b]; p.o1 = omega[3 * b + 1]; p.o2 = omega[3 * b + 2];
+    p.sx = (double)W * d / 2;
+    p.sy = (double)H * d / 2;
+    p.enabled = 1;
+    out[b] = p;
+}
+void launch_make_derot(hipStream_t st, const double* omega, const double* dt, int B, int W, int H, DerotParams* out)
+{
+    hipLaunchKernelGGL(k_make_derot, dim3((B + 63) / 64), dim3(64), 0, st, omega, dt, B, W, H, out);
+}

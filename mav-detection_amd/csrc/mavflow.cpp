@@ -543,28 +543,27 @@ static int ensure_foe_scratch(mav_ctx* c, int N)
     return MAV_OK;
 }
 
+// Per-pair derotation constants.  Device pointers stay on the device (a tiny kernel packs them: no host round trip, the
+// stream never drains); host pointers are packed here and copied.
 static int upload_derot(mav_ctx* c, const double* omega, const double* dt, int batch, bool host_ptrs, const DerotParams** out)
 {
     *out = nullptr;
     if (!omega) return MAV_OK;
-    std::vector<double> om(3 * (size_t)batch), dts((size_t)batch, 1.0);
-    if (host_ptrs) {
-        memcpy(om.data(), omega, sizeof(double) * 3 * batch);
-        if (dt) memcpy(dts.data(), dt, sizeof(double) * batch);
-    } else {
-        HIPCHK(hipMemcpyAsync(om.data(), omega, sizeof(double) * 3 * batch, hipMemcpyDeviceToHost, c->stream));
-        if (dt) HIPCHK(hipMemcpyAsync(dts.data(), dt, sizeof(double) * batch, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+    if (!host_ptrs) {
+        launch_make_derot(c->stream, omega, dt, batch, c->W, c->H, c->derot_dev);
+        *out = c->derot_dev;
+        return MAV_OK;
     }
     std::vector<DerotParams> dp(batch);
     for (int b = 0; b < batch; b++) {
-        dp[b].o0 = om[3 * b]; dp[b].o1 = om[3 * b + 1]; dp[b].o2 = om[3 * b + 2];
-        dp[b].sx = c->W * dts[b] / 2;   // w * dt / 2   (detector.py:101)
-        dp[b].sy = c->H * dts[b] / 2;
+        const double d = dt ? dt[b] : 1.0;
+        dp[b].o0 = omega[3 * b]; dp[b].o1 = omega[3 * b + 1]; dp[b].o2 = omega[3 * b + 2];
+        dp[b].sx = c->W * d / 2;   // w * dt / 2   (detector.py:101)
+        dp[b].sy = c->H * d / 2;
         dp[b].enabled = 1;
     }
     HIPCHK(hipMemcpyAsync(c->derot_dev, dp.data(), sizeof(DerotParams) * batch, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));  // dp is a stack vector
+    HIPCHK(hipStreamSynchronize(c->stream));  // dp is a local vector
     *out = c->derot_dev;
     return MAV_OK;
 }

@@ -80,3 +80,4 @@ void launch_tpr_fpr(hipStream_t st, const uint8_t* gt, const uint8_t* mask, int 
                     unsigned long long* counts /*[B][4]*/);
 void launch_bgr2gray(hipStream_t st, const uint8_t* bgr, size_t n, uint8_t* gray);
 void launch_ransac_only(hipStream_t st, FoeScratch s, int M, int N, double dist2_thr, double* foe);
+void launch_make_derot(hipStream_t st, const double* omega, const double* dt, int B, int W, int H, DerotParams* out);
