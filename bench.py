@@ -37,7 +37,7 @@ def b_alg_per_pair(layers, W, H, iters):
     return tot + 10 * P0
 
 
-def cpu_baseline(prev, nxt, samples, n_sample):
+def cpu_baseline(prev, nxt, samples, n_sample, gpu_flow_fn=None):
     """The CPU path on a bounded sample of the same workload, timed on this node's host cores (1 thread).
     Preferred: cv2.calcOpticalFlowFarneback (kind "reference") when OpenCV is importable on the node; otherwise the oracle's C
     restatement (kind "port", labelled as such).  The numpy FoE chain follows either."""
@@ -54,13 +54,22 @@ def cpu_baseline(prev, nxt, samples, n_sample):
         flow_fn = orc.calc
         kind, label = "port", "oracle/farneback_oracle.c (restatement, not OpenCV: cv2 is not importable on this node)"
     t0 = time.perf_counter()
+    flows = []
     for b in range(n_sample):
         flow = flow_fn(prev[b], nxt[b])
         foe_oracle.run_chain(flow, samples[b])
+        if b < 2:
+            flows.append(flow)
     dt = time.perf_counter() - t0
-    return {"value": n_sample / dt, "unit": "frame-pairs/s", "cores": 1, "kind": kind,
-            "sample": f"{n_sample} of the benchmark's {prev.shape[2]}x{prev.shape[1]} pairs, {label} + numpy FoE chain, {dt:.1f} s, "
-                      f"host has {os.cpu_count()} cores"}
+    out = {"value": n_sample / dt, "unit": "frame-pairs/s", "cores": 1, "kind": kind,
+           "sample": f"{n_sample} of the benchmark's {prev.shape[2]}x{prev.shape[1]} pairs, {label} + numpy FoE chain, {dt:.1f} s, "
+                     f"host has {os.cpu_count()} cores"}
+    if gpu_flow_fn is not None and flows:          # the metric's second half: end-point error of the GPU flow against the CPU flow
+        g = gpu_flow_fn(prev[:len(flows)], nxt[:len(flows)])
+        e = np.concatenate([np.hypot(g[i][..., 0] - f[..., 0], g[i][..., 1] - f[..., 1]).ravel() for i, f in enumerate(flows)])
+        out["flow_epe_px"] = {"mean": float(e.mean()), "p99.9": float(np.percentile(e, 99.9)), "max": float(e.max()),
+                              "against": "cv2" if kind == "reference" else "oracle restatement (cv2 absent)", "pairs": len(flows)}
+    return out
 
 
 def main():
@@ -213,7 +222,7 @@ def main():
         if roofline:
             out["roofline"] = roofline
         if world == 1 and args.cpu_pairs > 0:
-            out["cpu_baseline"] = cpu_baseline(prev, nxt, samples, min(args.cpu_pairs, B))
+            out["cpu_baseline"] = cpu_baseline(prev, nxt, samples, min(args.cpu_pairs, B), gpu_flow_fn=ctx.farneback)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
