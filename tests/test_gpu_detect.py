@@ -228,3 +228,38 @@ def test_bgr2gray(ctx_small):
     got = ctx_small.bgr2gray(bgr)
     assert np.array_equal(got, np.stack([bgr_to_gray(b) for b in bgr]))
     assert got[0, 0, :5].tolist() == [29, 150, 76, 255, 22]
+
+
+def test_foe_many_small_random_cases(mav):
+    """Sweep of small configurations (few pairs, integer-valued flows -> exact ties and parallel lines, all-skipped, one or two
+    survivors): the ordered compaction and the first-wins vote must match the oracle bit for bit in every one of them."""
+    from mavflow import _lib
+    W, H = 64, 48
+    rng = np.random.default_rng(123)
+    with _lib.Context(W, H, 8) as c:
+        for case in range(24):
+            n = int(rng.choice([1, 2, 3, 8, 33, 64, 100]))
+            p = _lib.foe_defaults()
+            p.n_pairs = n
+            p.mag_threshold = float(rng.choice([0.0, 1.5, 2.5]))
+            p.ransac_threshold = float(rng.choice([1.0, 5.0, 30.0]))
+            kind = case % 4
+            if kind == 0:      # integer flows: many exactly parallel pairs and exactly coincident intersections
+                fl = rng.integers(-3, 4, (8, H, W, 2)).astype(np.float64)
+            elif kind == 1:    # radial field: every intersection is the same point up to rounding
+                yy, xx = np.mgrid[0:H, 0:W]
+                one = np.stack([(xx - 30.0) * 0.25, (yy - 20.0) * 0.25], axis=-1)
+                fl = np.repeat(one[None], 8, axis=0)
+            elif kind == 2:    # mostly below the magnitude gate
+                fl = rng.normal(0, 0.4, (8, H, W, 2))
+            else:
+                fl = rng.normal(0, 3.0, (8, H, W, 2))
+                fl[:, ::7, ::5] = np.nan
+            smp = np.zeros((8, 2 * n, 2), np.uint32)
+            smp[..., 0] = rng.integers(0, H, (8, 2 * n))
+            smp[..., 1] = rng.integers(0, W, (8, 2 * n))
+            got = c.foe_dense(fl, smp, p)
+            for b in range(8):
+                with np.errstate(all="ignore"):
+                    exp = fo.get_foe_dense(fl[b], smp[b], p.mag_threshold, p.ransac_threshold)
+                assert got[b].tobytes() == np.array(exp, np.float64).tobytes(), (case, b, n, tuple(got[b]), exp)
