@@ -13,6 +13,25 @@
 
 static __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+#ifdef MAV_STAMPS   // diagnostic build only (tools/phase_stamps.py): per-phase wave cycles of the sweep kernel, never in the product .so
+#define MAV_STAMP_WAVES (1 << 17)
+__device__ unsigned long long g_phase_cycles[MAV_STAMP_WAVES * 8];   // one row per wave slot of a launch: plain += (launches are serial)
+#define STAMP(var) unsigned long long var; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0)
+#define STAMP_ADD(i, a, b) do { if ((threadIdx.x & 63) == 0) { const unsigned wid = (blockIdx.x * 4u + (threadIdx.x >> 6)) & (MAV_STAMP_WAVES - 1); g_phase_cycles[wid * 8 + (i)] += (unsigned long long)((b) - (a)); } } while (0)
+extern "C" int mav_debug_read_stamps(unsigned long long* out, int reset)
+{
+    static unsigned long long host[MAV_STAMP_WAVES * 8];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_phase_cycles), sizeof(host)) != hipSuccess) return -1;
+    for (int i = 0; i < 8; i++) out[i] = 0;
+    for (size_t w = 0; w < MAV_STAMP_WAVES; w++) for (int i = 0; i < 8; i++) out[i] += host[w * 8 + i];
+    if (reset) { static unsigned long long z[MAV_STAMP_WAVES * 8]; if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define STAMP(var)
+#define STAMP_ADD(i, a, b)
+#endif
+
 // ------------------------------------------------------------------------------------------------------------
 // Layer image: convertTo(f32) -> GaussianBlur(ksize, sigma, REFLECT_101) -> resize(INTER_LINEAR)   (A.2).
 // ------------------------------------------------------------------------------------------------------------
@@ -608,6 +627,7 @@ __global__ __launch_bounds__(256) void k_blur_iter_fast(const float* __restrict_
     const float* R0p = R0 + (size_t)s * R_stride;
     const float* R1p = R1 + (size_t)s * R_stride;
 
+    STAMP(ts0);
     // entry: R0 of this thread's four phase-C pixels (rows 4*wv + j, column lane)
     float q[4][5];
     int gys[4];
@@ -663,7 +683,9 @@ __global__ __launch_bounds__(256) void k_blur_iter_fast(const float* __restrict_
             }
         }
     }
+    STAMP(ts1);
     __syncthreads();
+    STAMP(ts2);
 
     {
         // hardware b128 lane group (quads of 4 lanes: g0 = quads {0,3,5,6}, g1 = quads {1,2,4,7}, +2 for lanes 32..63)
@@ -713,6 +735,7 @@ __global__ __launch_bounds__(256) void k_blur_iter_fast(const float* __restrict_
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    STAMP(ts3);
 
     float* Mo = M_out + (size_t)s * M_stride;
     const bool colok = x0 + lane < w;
@@ -737,7 +760,12 @@ __global__ __launch_bounds__(256) void k_blur_iter_fast(const float* __restrict_
                 for (int c = 0; c < 5; c++) Mo[c * npx + idx] = o[c];
             }
         }
+#ifdef MAV_STAMPS
+        if (jb == 0) { STAMP(tsm); STAMP_ADD(3, ts3, tsm); STAMP_ADD(5, tsm, tsm); }
+#endif
     }
+    STAMP(ts4);
+    STAMP_ADD(0, ts0, ts1); STAMP_ADD(1, ts1, ts2); STAMP_ADD(2, ts2, ts3); STAMP_ADD(4, ts3, ts4); STAMP_ADD(6, ts0, ts4); STAMP_ADD(7, 0ull, 1ull);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(HERE, "libmavflow.so")
+SO_PATH = os.environ.get("MAVFLOW_SO", os.path.join(HERE, "libmavflow.so"))   # override: diagnostic builds only
 
 MAV_OK, MAV_ERR_ARG, MAV_ERR_HIP, MAV_ERR_OOM, MAV_ERR_STATE = 0, -1, -2, -3, -4
 
