@@ -204,3 +204,13 @@ def test_flow_vs_cv2_when_available(ctx640, pair640):
     ref = cv2.calcOpticalFlowFarneback(pair640[0], pair640[1], None, 0.4, 1, 12, 10, 8, 1.2, 0)
     got = ctx640.farneback(pair640[0], pair640[1])[0]
     _check_flow(got, ref, "vs cv2")
+
+
+def test_shape_and_parameter_fuzz(mav):
+    """tools/fuzz_shapes.py, 15 cases: random sizes (multiples of 4 and not), batch sizes, pyramid / window / poly parameters
+    and noise frames through the fused entry point -- flow within the EPE gate, FoE / masks / boxes bit-exact."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_shapes.py"), "15", "7"], cwd=root, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0 and "all 15 cases passed" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
