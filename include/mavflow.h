@@ -127,6 +127,13 @@ int mav_dev_free(mav_ctx*, void* p);
 int mav_memcpy_h2d(mav_ctx*, void* dst, const void* src, size_t bytes);
 int mav_memcpy_d2h(mav_ctx*, void* dst, const void* src, size_t bytes);
 
+/* Overlapped uploads: pinned host memory, copies on a second stream, and a fence that makes everything enqueued on the
+ * context's stream AFTER the fence wait for the copies issued BEFORE it (double-buffered batches hide PCIe). */
+int mav_host_alloc(mav_ctx*, size_t bytes, void** out);
+int mav_host_free(mav_ctx*, void* p);
+int mav_upload_async(mav_ctx*, void* dst_dev, const void* src_host, size_t bytes);
+int mav_upload_fence(mav_ctx*);
+
 /* HIP-event timing on the context's stream (bench.py): start/stop bracket enqueued work; stop synchronises. */
 int mav_timer_start(mav_ctx*);
 int mav_timer_stop(mav_ctx*, float* ms);

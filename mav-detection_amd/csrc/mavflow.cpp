@@ -174,6 +174,8 @@ struct mav_ctx {
     bool use_rc = false;         // option "recompute": sweeps rebuild M on the fly (k_sweep_rc) instead of storing it
     mav_fb_params fb;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;   // uploads that overlap the compute stream (mav_upload_async / mav_upload_fence)
+    hipEvent_t copy_done = nullptr;
     std::vector<Layer> layers;
     PolyCoef pc;
     // workspace (group slots)
@@ -244,6 +246,8 @@ extern "C" int mav_destroy(mav_ctx* c)
     for (auto& r : c->prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     if (c->t0) hipEventDestroy(c->t0);
     if (c->t1) hipEventDestroy(c->t1);
+    if (c->copy_done) hipEventDestroy(c->copy_done);
+    if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
     return MAV_OK;
@@ -273,6 +277,8 @@ extern "C" int mav_create(mav_ctx** out, int device, int W, int H, int max_batch
     auto bail = [&](int code) { mav_destroy(c); return code; };
 #define HIPB(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fail(e_ == hipErrorOutOfMemory ? MAV_ERR_OOM : MAV_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); return bail(e_ == hipErrorOutOfMemory ? MAV_ERR_OOM : MAV_ERR_HIP); } } while (0)
     HIPB(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPB(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    HIPB(hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming));
     HIPB(hipEventCreate(&c->t0));
     HIPB(hipEventCreate(&c->t1));
     if (!prepare_poly(fb.poly_n, fb.poly_sigma, &c->pc)) { fail(MAV_ERR_ARG, "poly_sigma %g gives a singular moment matrix", fb.poly_sigma); return bail(MAV_ERR_ARG); }
@@ -387,6 +393,34 @@ extern "C" int mav_memcpy_d2h(mav_ctx* c, void* dst, const void* src, size_t byt
     if (!c || !dst || !src) return fail(MAV_ERR_ARG, "mav_memcpy_d2h: NULL argument");
     HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    return MAV_OK;
+}
+
+// Pinned host memory + uploads on a second stream: the next batch's frames cross PCIe while the current batch computes.
+extern "C" int mav_host_alloc(mav_ctx* c, size_t bytes, void** out)
+{
+    if (!c || !out) return fail(MAV_ERR_ARG, "mav_host_alloc: NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return MAV_OK;
+}
+extern "C" int mav_host_free(mav_ctx* c, void* p)
+{
+    if (!c) return fail(MAV_ERR_ARG, "mav_host_free: NULL context");
+    if (p) HIPCHK(hipHostFree(p));
+    return MAV_OK;
+}
+extern "C" int mav_upload_async(mav_ctx* c, void* dst_dev, const void* src_host, size_t bytes)
+{
+    if (!c || !dst_dev || !src_host) return fail(MAV_ERR_ARG, "mav_upload_async: NULL argument");
+    HIPCHK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->copy_stream));
+    return MAV_OK;
+}
+extern "C" int mav_upload_fence(mav_ctx* c)
+{
+    if (!c) return fail(MAV_ERR_ARG, "mav_upload_fence: NULL context");
+    HIPCHK(hipEventRecord(c->copy_done, c->copy_stream));
+    HIPCHK(hipStreamWaitEvent(c->stream, c->copy_done, 0));   // work enqueued after this call sees the uploaded bytes
     return MAV_OK;
 }
 

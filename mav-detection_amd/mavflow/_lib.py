@@ -44,7 +44,7 @@ EXPORTS = [
     "mav_device_count", "mav_set_option", "mav_num_layers", "mav_layer_dims", "mav_farneback", "mav_derotate",
     "mav_foe_dense", "mav_ransac", "mav_bgr2gray", "mav_phi_mask", "mav_bbox", "mav_window_max", "mav_tpr_fpr_counts", "mav_process_batch",
     "mav_farneback_dev", "mav_process_batch_dev", "mav_sync", "mav_stream", "mav_dev_alloc", "mav_dev_free",
-    "mav_memcpy_h2d", "mav_memcpy_d2h", "mav_timer_start", "mav_timer_stop", "mav_profile_enable", "mav_profile_get",
+    "mav_memcpy_h2d", "mav_memcpy_d2h", "mav_host_alloc", "mav_host_free", "mav_upload_async", "mav_upload_fence", "mav_timer_start", "mav_timer_stop", "mav_profile_enable", "mav_profile_get",
     "mav_comm_unique_id", "mav_comm_init", "mav_comm_destroy", "mav_allgather_results", "mav_stage_blur_resize",
     "mav_stage_polyexp", "mav_stage_update_matrices", "mav_stage_blur_iter",
 ]
@@ -91,6 +91,10 @@ def load() -> C.CDLL:
     lib.mav_dev_free.argtypes = [vp, vp]
     lib.mav_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
     lib.mav_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.mav_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    lib.mav_host_free.argtypes = [vp, vp]
+    lib.mav_upload_async.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.mav_upload_fence.argtypes = [vp]
     lib.mav_timer_start.argtypes = [vp]
     lib.mav_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
     lib.mav_profile_enable.argtypes = [vp, C.c_int]
@@ -192,6 +196,9 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None):
+            for p in getattr(self, "_pinned", []):
+                self.lib.mav_host_free(self.h, p)
+            self._pinned = []
             self.lib.mav_destroy(self.h)
             self.h = None
 
@@ -224,6 +231,21 @@ class Context:
 
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)
+
+    def pinned_like(self, a: np.ndarray) -> np.ndarray:
+        """A page-locked host copy of `a` (numpy view over hipHostMalloc memory; freed with the context)."""
+        p = C.c_void_p()
+        check(self.lib.mav_host_alloc(self.h, a.nbytes, C.byref(p)))
+        self._pinned = getattr(self, "_pinned", []) + [p.value]
+        out = np.ctypeslib.as_array((C.c_uint8 * a.nbytes).from_address(p.value)).view(a.dtype).reshape(a.shape)
+        out[...] = a
+        return out
+
+    def upload_async(self, dst: DeviceBuffer, src: np.ndarray):
+        check(self.lib.mav_upload_async(self.h, dst.ptr, _ptr(src), src.nbytes))
+
+    def upload_fence(self):
+        check(self.lib.mav_upload_fence(self.h))
 
     # -- host-array entry points -----------------------------------------------------------------------------
     def _imgs(self, a, name):
