@@ -263,3 +263,25 @@ def test_foe_many_small_random_cases(mav):
                 with np.errstate(all="ignore"):
                     exp = fo.get_foe_dense(fl[b], smp[b], p.mag_threshold, p.ransac_threshold)
                 assert got[b].tobytes() == np.array(exp, np.float64).tobytes(), (case, b, n, tuple(got[b]), exp)
+
+
+def test_rccl_allgather_entry_points_world_size_1(mav):
+    """mav_comm_* / mav_allgather_results (RCCL loaded lazily by the library, no torch): a one-rank communicator must return
+    the local records unchanged -- exercises the dlopen path and the by-value ncclUniqueId calling convention."""
+    import ctypes as C
+    from mavflow import _lib
+    with _lib.Context(160, 120, 4) as c:
+        uid = (C.c_char * 128)()
+        _lib.check(c.lib.mav_comm_unique_id(uid))
+        comm = C.c_void_p()
+        _lib.check(c.lib.mav_comm_init(c.h, uid, 0, 1, C.byref(comm)))
+        rec = np.zeros(4, _lib.RESULT_DTYPE)
+        rec["box"] = np.arange(16).reshape(4, 4)
+        rec["foe"] = np.arange(8).reshape(4, 2) * 0.5
+        src = c.alloc(rec.nbytes).upload(rec)
+        dst = c.alloc(rec.nbytes)
+        _lib.check(c.lib.mav_allgather_results(c.h, comm, src.ptr, rec.nbytes, dst.ptr))
+        c.sync()
+        got = dst.download(_lib.RESULT_DTYPE, (4,))
+        _lib.check(c.lib.mav_comm_destroy(comm))
+    assert got.tobytes() == rec.tobytes()
