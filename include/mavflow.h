@@ -102,6 +102,21 @@ int mav_bbox(mav_ctx*, const uint8_t* img, int batch, int32_t* box);
 /* Level 0 of Detector.analyze_pyramid [src/detector.py:280-312] on the 3-channel replica of a u8 image:
  * out (batch,3) = score, x, y of the first 64x64 / stride-16 window with the strictly largest sum. */
 int mav_window_max(mav_ctx*, const uint8_t* img, int batch, int64_t* out);
+/* Detector.analyze_pyramid [src/detector.py:280-312] over ALL levels of pyramid() [src/im_helpers.py:12-35; each level =
+ * imutils.resize(previous, width=int(w/scale)) = cv2.resize(INTER_AREA), until a side drops below 30 px] with
+ * sliding_window() [src/im_helpers.py:38-52], on the 3-channel replica of a u8 image (the reference passes scale 1.5).
+ * out (batch,6) = score, x, y, level, argmax_row, argmax_col: the first window in scan order (level 0 first) with the
+ * strictly largest sum; x, y in that level's own coordinates (the reference does not rescale them); argmax = position of
+ * the window's first maximum (np.unravel_index(window.argmax(), ...)); all 0 when no window has a positive sum.
+ * MAV_ERR_ARG when scale <= 1 or a level's size ratio is a whole number in both axes (OpenCV's fast-area path). */
+int mav_analyze_pyramid(mav_ctx*, const uint8_t* img, int batch, double scale, int64_t* out);
+int mav_pyramid_levels(const mav_ctx*, double scale);                          /* number of levels (>= 1), or MAV_ERR_* */
+int mav_pyramid_dims(const mav_ctx*, double scale, int level, int* w, int* h); /* size of level `level` */
+/* Detector.optimize_window [src/detector.py:314-358] on the 3-channel replica of a u8 image: greedy growth / shrink of a
+ * window by moving one corner diagonally by one pixel per step while the enclosed sum rises (Python slice semantics for
+ * windows that leave the image).  window_in / window_out (batch,4) = x, y, w, h; score (batch) = 3 * enclosed sum, 0 and the
+ * unchanged window when no neighbour has a positive sum. */
+int mav_optimize_window(mav_ctx*, const uint8_t* img, int batch, const int32_t* window_in, int64_t* score, int32_t* window_out);
 /* im_helpers.calculate_tpr_fpr [src/im_helpers.py:244-252] for a 0/255 ground truth and a 0/1 mask:
  * counts (batch,4) = positives, negatives, true positives, false positives. */
 int mav_tpr_fpr_counts(mav_ctx*, const uint8_t* gt, const uint8_t* mask, int batch, int64_t* counts);
@@ -159,6 +174,9 @@ int mav_stage_update_matrices(mav_ctx*, const float* R0, const float* R1, const 
 /* one FarnebackUpdateFlow_Blur sweep at layer k: M (5,h,w) -> flow (h,w,2) and, if update != 0, M_out (5,h,w) */
 int mav_stage_blur_iter(mav_ctx*, const float* R0, const float* R1, const float* M, int k, int update, float* flow,
                         float* M_out);
+
+/* pyramid level `level` (>= 0) of one u8 image: (h_l, w_l) u8, sizes from mav_pyramid_dims */
+int mav_stage_pyramid_level(mav_ctx*, const uint8_t* img, double scale, int level, uint8_t* out);
 
 #ifdef __cplusplus
 }

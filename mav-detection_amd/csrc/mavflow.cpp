@@ -192,6 +192,9 @@ struct mav_ctx {
     unsigned long long* u64_scratch = nullptr;  // [max_batch*4]
     int* i32_scratch = nullptr;                 // [max_batch]
     DerotParams* derot_dev = nullptr;
+    uint8_t* pyr_ws = nullptr;                  // analyze_pyramid level images (lazily, max_batch)
+    size_t pyr_ws_bytes = 0;
+    unsigned long long* sat = nullptr;          // optimize_window summed-area tables (lazily, max_batch)
     hipEvent_t t0 = nullptr, t1 = nullptr;
     bool profiling = false;
     std::vector<ProfRec> prof;
@@ -241,7 +244,7 @@ extern "C" int mav_destroy(mav_ctx* c)
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto& l : c->layers) free_layer(l);
     void* bufs[] = {c->I, c->R0, c->R1, c->Ma, c->Mb, c->fc[0], c->fc[1], c->Htmp, c->flow_ws, c->foe_sc.cand, c->foe_sc.count,
-                    c->foe_sc.best_key, c->foe_dev, c->box_acc, c->u64_scratch, c->i32_scratch, c->derot_dev};
+                    c->foe_sc.best_key, c->foe_dev, c->box_acc, c->u64_scratch, c->i32_scratch, c->derot_dev, c->pyr_ws, c->sat};
     for (void* b : bufs) if (b) hipFree(b);
     for (auto& r : c->prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     if (c->t0) hipEventDestroy(c->t0);
@@ -807,6 +810,134 @@ extern "C" int mav_window_max(mav_ctx* c, const uint8_t* img, int batch, int64_t
     launch_window_max(c->stream, di.as<uint8_t>(), batch, c->W, c->H, c->u64_scratch, dout.as<int64_t>());
     CHK(check_launch("window_max"));
     CHK(download(c, out, dout.p, sizeof(int64_t) * 3 * batch));
+    return mav_sync(c);
+}
+
+// ---- window search: analyze_pyramid / optimize_window -----------------------------------------------------------
+// Level sizes exactly as the reference derives them (im_helpers.py:28-33 + imutils.resize): w' = int(w / scale),
+// r = w' / float(w), h' = int(h * r); stop when a side drops below 30.
+static int pyr_plan(const mav_ctx* c, double scale, int batch_cap, PyrPlan* p)
+{
+    if (!(scale > 1.0)) return fail(MAV_ERR_ARG, "pyramid scale %g must be > 1", scale);
+    int w = c->W, h = c->H;
+    size_t off = 0;
+    unsigned base = 0;
+    p->n = 0;
+    for (;;) {
+        if (p->n == MAV_PYR_MAX) return fail(MAV_ERR_ARG, "pyramid scale %g gives more than %d levels", scale, MAV_PYR_MAX);
+        const int n = p->n++;
+        p->w[n] = w; p->h[n] = h; p->base[n] = base; p->off[n] = off;
+        if (w >= 64 && h >= 64) base += (unsigned)(((w - 64) / 16 + 1) * ((h - 64) / 16 + 1));
+        if (n > 0) off += ((size_t)w * h * batch_cap + 255) & ~(size_t)255;
+        const int wn = (int)((double)w / scale);
+        if (wn < 1) break;
+        const double r = (double)wn / (double)w;
+        const int hn = (int)((double)h * r);
+        if (hn < 30 || wn < 30) break;
+        // cv2.resize takes its integer-ratio "fast area" path when both ratios are whole numbers; only the general path is restated
+        const double sx = 1.0 / ((double)wn / w), sy = 1.0 / ((double)hn / h);
+        if (fabs(sx - (int)sx) < DBL_EPSILON && fabs(sy - (int)sy) < DBL_EPSILON)
+            return fail(MAV_ERR_ARG, "pyramid level %d -> %d has an integer ratio (%dx%d -> %dx%d): OpenCV's fast-area path is not implemented",
+                        n, n + 1, w, h, wn, hn);
+        w = wn; h = hn;
+    }
+    p->base[p->n] = base;
+    return MAV_OK;
+}
+static size_t pyr_bytes(const PyrPlan& p, int batch_cap)
+{
+    size_t total = 0;
+    for (int l = 1; l < p.n; l++) total += ((size_t)p.w[l] * p.h[l] * batch_cap + 255) & ~(size_t)255;
+    return total ? total : 256;
+}
+static int ensure_pyr_ws(mav_ctx* c, const PyrPlan& p)
+{
+    const size_t need = pyr_bytes(p, c->max_batch);
+    if (need <= c->pyr_ws_bytes) return MAV_OK;
+    if (c->pyr_ws) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(c->pyr_ws); }
+    c->pyr_ws = nullptr; c->pyr_ws_bytes = 0;
+    if (hipMalloc(&c->pyr_ws, need) != hipSuccess) return fail(MAV_ERR_OOM, "pyramid workspace (%zu bytes)", need);
+    c->pyr_ws_bytes = need;
+    return MAV_OK;
+}
+// levels 1 .. upto of `batch` images (device pointer img0) into the workspace
+static void build_pyramid(mav_ctx* c, const PyrPlan& p, const uint8_t* img0, int batch, int upto)
+{
+    for (int l = 1; l <= upto && l < p.n; l++) {
+        const uint8_t* src = l == 1 ? img0 : c->pyr_ws + p.off[l - 1];
+        launch_area_resize(c->stream, src, (size_t)p.w[l - 1] * p.h[l - 1], p.w[l - 1], p.h[l - 1], c->pyr_ws + p.off[l],
+                           (size_t)p.w[l] * p.h[l], p.w[l], p.h[l], batch);
+    }
+}
+
+extern "C" int mav_pyramid_levels(const mav_ctx* c, double scale)
+{
+    if (!c) return fail(MAV_ERR_ARG, "mav_pyramid_levels: NULL context");
+    PyrPlan p;
+    CHK(pyr_plan(c, scale, 1, &p));
+    return p.n;
+}
+extern "C" int mav_pyramid_dims(const mav_ctx* c, double scale, int level, int* w, int* h)
+{
+    if (!c) return fail(MAV_ERR_ARG, "mav_pyramid_dims: NULL context");
+    PyrPlan p;
+    CHK(pyr_plan(c, scale, 1, &p));
+    if (level < 0 || level >= p.n) return fail(MAV_ERR_ARG, "pyramid level %d outside [0, %d)", level, p.n);
+    if (w) *w = p.w[level];
+    if (h) *h = p.h[level];
+    return MAV_OK;
+}
+
+extern "C" int mav_analyze_pyramid(mav_ctx* c, const uint8_t* img, int batch, double scale, int64_t* out)
+{
+    CHK(check_batch(c, batch, "mav_analyze_pyramid"));
+    if (!img || !out) return fail(MAV_ERR_ARG, "mav_analyze_pyramid: NULL argument");
+    PyrPlan p;
+    CHK(pyr_plan(c, scale, c->max_batch, &p));
+    CHK(ensure_pyr_ws(c, p));
+    DevBuf di, dout;
+    CHK(di.upload(c, img, c->n0 * batch)); CHK(dout.alloc(sizeof(int64_t) * 6 * batch));
+    HIPCHK(hipMemsetAsync(c->u64_scratch, 0, sizeof(unsigned long long) * batch, c->stream));
+    build_pyramid(c, p, di.as<uint8_t>(), batch, p.n - 1);
+    for (int l = 0; l < p.n; l++)
+        launch_level_scan(c->stream, l == 0 ? di.as<uint8_t>() : c->pyr_ws + p.off[l], (size_t)p.w[l] * p.h[l], batch, p.w[l], p.h[l],
+                          p.base[l], c->u64_scratch);
+    launch_pyramid_finalize(c->stream, c->u64_scratch, p, di.as<uint8_t>(), c->pyr_ws, batch, dout.as<int64_t>());
+    CHK(check_launch("analyze_pyramid"));
+    CHK(download(c, out, dout.p, sizeof(int64_t) * 6 * batch));
+    return mav_sync(c);
+}
+
+extern "C" int mav_stage_pyramid_level(mav_ctx* c, const uint8_t* img, double scale, int level, uint8_t* out)
+{
+    CHK(check_batch(c, 1, "mav_stage_pyramid_level"));
+    if (!img || !out) return fail(MAV_ERR_ARG, "mav_stage_pyramid_level: NULL argument");
+    PyrPlan p;
+    CHK(pyr_plan(c, scale, c->max_batch, &p));
+    if (level < 0 || level >= p.n) return fail(MAV_ERR_ARG, "pyramid level %d outside [0, %d)", level, p.n);
+    CHK(ensure_pyr_ws(c, p));
+    DevBuf di;
+    CHK(di.upload(c, img, c->n0));
+    build_pyramid(c, p, di.as<uint8_t>(), 1, level);
+    CHK(check_launch("area_resize"));
+    CHK(download(c, out, level == 0 ? di.p : (void*)(c->pyr_ws + p.off[level]), (size_t)p.w[level] * p.h[level]));
+    return mav_sync(c);
+}
+
+extern "C" int mav_optimize_window(mav_ctx* c, const uint8_t* img, int batch, const int32_t* window_in, int64_t* score,
+                                   int32_t* window_out)
+{
+    CHK(check_batch(c, batch, "mav_optimize_window"));
+    if (!img || !window_in || !score || !window_out) return fail(MAV_ERR_ARG, "mav_optimize_window: NULL argument");
+    if (!c->sat && hipMalloc(&c->sat, sizeof(unsigned long long) * (size_t)(c->W + 1) * (c->H + 1) * c->max_batch) != hipSuccess)
+        return fail(MAV_ERR_OOM, "summed-area tables");
+    DevBuf di, dw, ds, dwo;
+    CHK(di.upload(c, img, c->n0 * batch)); CHK(dw.upload(c, window_in, sizeof(int32_t) * 4 * batch));
+    CHK(ds.alloc(sizeof(int64_t) * batch)); CHK(dwo.alloc(sizeof(int32_t) * 4 * batch));
+    launch_optimize_window(c->stream, di.as<uint8_t>(), batch, c->W, c->H, c->sat, dw.as<int32_t>(), ds.as<int64_t>(), dwo.as<int32_t>());
+    CHK(check_launch("optimize_window"));
+    CHK(download(c, score, ds.p, sizeof(int64_t) * batch));
+    CHK(download(c, window_out, dwo.p, sizeof(int32_t) * 4 * batch));
     return mav_sync(c);
 }
 

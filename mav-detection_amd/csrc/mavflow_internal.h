@@ -81,3 +81,22 @@ void launch_tpr_fpr(hipStream_t st, const uint8_t* gt, const uint8_t* mask, int 
 void launch_bgr2gray(hipStream_t st, const uint8_t* bgr, size_t n, uint8_t* gray);
 void launch_ransac_only(hipStream_t st, FoeScratch s, int M, int N, double dist2_thr, double* foe);
 void launch_make_derot(hipStream_t st, const double* omega, const double* dt, int B, int W, int H, DerotParams* out);
+
+// ---- window search (kernels_window.hip, compiled with -ffp-contract=off) -----------------------------------------
+#define MAV_PYR_MAX 32
+// Levels of analyze_pyramid for one frame size: dims, first window index of each level in the reference's scan order
+// (base[n] = total), and the byte offset of a level's image block (levels >= 1, batch images back to back) in the workspace.
+struct PyrPlan {
+    int n;
+    int w[MAV_PYR_MAX], h[MAV_PYR_MAX];
+    unsigned base[MAV_PYR_MAX + 1];
+    size_t off[MAV_PYR_MAX];
+};
+void launch_area_resize(hipStream_t st, const uint8_t* src, size_t src_stride, int sw, int sh, uint8_t* dst, size_t dst_stride,
+                        int dw, int dh, int B);
+void launch_level_scan(hipStream_t st, const uint8_t* img, size_t stride, int B, int W, int H, unsigned idx_base,
+                       unsigned long long* key /*[B], zeroed by the caller*/);
+void launch_pyramid_finalize(hipStream_t st, const unsigned long long* key, const PyrPlan& plan, const uint8_t* img0,
+                             const uint8_t* ws, int B, int64_t* out /*[B][6]*/);
+void launch_optimize_window(hipStream_t st, const uint8_t* img, int B, int W, int H, unsigned long long* sat /*[B][(H+1)(W+1)]*/,
+                            const int32_t* win_in, int64_t* score, int32_t* win_out);

@@ -47,6 +47,7 @@ EXPORTS = [
     "mav_memcpy_h2d", "mav_memcpy_d2h", "mav_host_alloc", "mav_host_free", "mav_upload_async", "mav_upload_fence", "mav_timer_start", "mav_timer_stop", "mav_profile_enable", "mav_profile_get",
     "mav_comm_unique_id", "mav_comm_init", "mav_comm_destroy", "mav_allgather_results", "mav_stage_blur_resize",
     "mav_stage_polyexp", "mav_stage_update_matrices", "mav_stage_blur_iter",
+    "mav_analyze_pyramid", "mav_pyramid_levels", "mav_pyramid_dims", "mav_optimize_window", "mav_stage_pyramid_level",
 ]
 
 _lib = None
@@ -82,6 +83,11 @@ def load() -> C.CDLL:
     lib.mav_bbox.argtypes = [vp, vp, C.c_int, vp]
     lib.mav_window_max.argtypes = [vp, vp, C.c_int, vp]
     lib.mav_tpr_fpr_counts.argtypes = [vp, vp, vp, C.c_int, vp]
+    lib.mav_analyze_pyramid.argtypes = [vp, vp, C.c_int, C.c_double, vp]
+    lib.mav_pyramid_levels.argtypes = [vp, C.c_double]
+    lib.mav_pyramid_dims.argtypes = [vp, C.c_double, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.mav_optimize_window.argtypes = [vp, vp, C.c_int, vp, vp, vp]
+    lib.mav_stage_pyramid_level.argtypes = [vp, vp, C.c_double, C.c_int, vp]
     pb = [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.POINTER(FoeParams), C.POINTER(ThrParams), vp, vp, vp, vp, vp]
     lib.mav_process_batch.argtypes = pb
     lib.mav_process_batch_dev.argtypes = pb
@@ -330,6 +336,43 @@ class Context:
         out = np.empty((img.shape[0], 3), np.int64)
         check(self.lib.mav_window_max(self.h, _ptr(img), img.shape[0], _ptr(out)))
         return out
+
+    def pyramid_dims(self, scale: float = 1.5):
+        """[(w, h)] of every level of im_helpers.pyramid for this frame size."""
+        n = self.lib.mav_pyramid_levels(self.h, scale)
+        if n < 0:
+            check(n)
+        dims = []
+        for l in range(n):
+            w, h = C.c_int(), C.c_int()
+            check(self.lib.mav_pyramid_dims(self.h, scale, l, C.byref(w), C.byref(h)))
+            dims.append((w.value, h.value))
+        return dims
+
+    def analyze_pyramid(self, img, scale: float = 1.5) -> np.ndarray:
+        """(batch, 6) int64: score, x, y, level, argmax_row, argmax_col (detector.py:280-312, all levels)."""
+        img = self._imgs(img, "img")
+        out = np.empty((img.shape[0], 6), np.int64)
+        check(self.lib.mav_analyze_pyramid(self.h, _ptr(img), img.shape[0], scale, _ptr(out)))
+        return out
+
+    def pyramid_level(self, img, level: int, scale: float = 1.5) -> np.ndarray:
+        img = self._imgs(img, "img")
+        w, h = C.c_int(), C.c_int()
+        check(self.lib.mav_pyramid_dims(self.h, scale, level, C.byref(w), C.byref(h)))
+        out = np.empty((h.value, w.value), np.uint8)
+        check(self.lib.mav_stage_pyramid_level(self.h, _ptr(img[:1]), scale, level, _ptr(out)))
+        return out
+
+    def optimize_window(self, img, windows):
+        """Detector.optimize_window (detector.py:314-358): windows (batch, 4) = x, y, w, h -> (scores int64, windows int32)."""
+        img = self._imgs(img, "img")
+        B = img.shape[0]
+        win = _arr(np.asarray(windows).reshape(B, 4), np.int32)
+        score = np.empty(B, np.int64)
+        out = np.empty((B, 4), np.int32)
+        check(self.lib.mav_optimize_window(self.h, _ptr(img), B, _ptr(win), _ptr(score), _ptr(out)))
+        return score, out
 
     def tpr_fpr_counts(self, gt, mask) -> np.ndarray:
         gt = self._imgs(gt, "gt")

@@ -1,5 +1,5 @@
-"""Detector -- the Algorithm switch, IMU derotation and the level-0 window search of the reference's Detector
-(/root/reference/src/detector.py:14-117,280-312,430-433) on libmavflow.  The homography / affine / essential-matrix
+"""Detector -- the Algorithm switch, IMU derotation and the window search (analyze_pyramid, optimize_window) of the
+reference's Detector (/root/reference/src/detector.py:14-117,280-358,430-433) on libmavflow.  The homography / affine / essential-matrix
 branches (cv2 RANSAC estimators, dead in run_detection) are not part of the hot path."""
 from __future__ import annotations
 
@@ -60,24 +60,44 @@ class Detector:
         W, H = self.dataset.capture_size[0], self.dataset.capture_size[1]
         return im_helpers._ctx(W, H).derotate(np.asarray(flow_uv, np.float32), omega, dt)[0]
 
-    def analyze_pyramid(self, img: np.ndarray) -> Tuple[float, utils.Rectangle, np.ndarray, Any]:
-        """Highest-sum 64x64 window (stride 16, first maximum wins) of pyramid level 0.
-        Returns (score, Rectangle, window, argmax inside the window) like the reference."""
+    @staticmethod
+    def _gray_of(img: np.ndarray, who: str):
         a = np.asarray(img)
         if a.dtype != np.uint8:
-            raise TypeError("analyze_pyramid expects the u8 image im_helpers.to_rgb produces")
+            raise TypeError(f"{who} expects the u8 image im_helpers.to_rgb produces")
         if a.ndim == 3:
             if not (np.array_equal(a[..., 0], a[..., 1]) and np.array_equal(a[..., 0], a[..., 2])):
-                raise ValueError("analyze_pyramid: 3-channel input must be a gray replica (im_helpers.to_rgb)")
-            gray, mult = np.ascontiguousarray(a[..., 0]), 1
-        else:
-            gray, mult = a, 3
+                raise ValueError(f"{who}: 3-channel input must be a gray replica (im_helpers.to_rgb)")
+            return a, np.ascontiguousarray(a[..., 0]), 1
+        return a, a, 3
+
+    def analyze_pyramid(self, img: np.ndarray) -> Tuple[float, utils.Rectangle, np.ndarray, Any]:
+        """Highest-sum 64x64 window (stride 16, first maximum wins) over every pyramid level (scale 1.5, INTER_AREA).
+        Returns (score, Rectangle, window, argmax inside the window) like the reference (detector.py:280-312): the
+        rectangle is in the winning level's own coordinates and `window` is that level's sub-image."""
+        a, gray, mult = self._gray_of(img, "analyze_pyramid")
         H, W = gray.shape
-        score, x, y = (int(v) for v in im_helpers._ctx(W, H).window_max(gray)[0])
+        ctx = im_helpers._ctx(W, H)
+        score, x, y, level, ay, ax = (int(v) for v in ctx.analyze_pyramid(gray)[0])
         if score == 0:
             return (0, utils.Rectangle((0, 0), (0, 0)), np.zeros(0), 0)
-        window = a[y:y + 64, x:x + 64]
-        return (score // mult, utils.Rectangle((x, y), (64, 64)), window, np.unravel_index(window.argmax(), window.shape))
+        lv = gray if level == 0 else ctx.pyramid_level(gray, level)
+        window = lv[y:y + 64, x:x + 64]
+        if a.ndim == 3:
+            window = np.repeat(window[..., None], 3, axis=2)
+        return (score // mult, utils.Rectangle((x, y), (64, 64)), window, (ay, ax, 0) if a.ndim == 3 else (ay, ax))
+
+    def optimize_window(self, mag_img: np.ndarray, window: utils.Rectangle) -> Tuple[float, utils.Rectangle]:
+        """Greedy corner walk of detector.py:314-358 (the window grows / shrinks while the enclosed sum rises)."""
+        a, gray, mult = self._gray_of(mag_img, "optimize_window")
+        H, W = gray.shape
+        win = [int(window.get_left()), int(window.get_top()), int(window.get_right()) - int(window.get_left()),
+               int(window.get_bottom()) - int(window.get_top())]
+        score, out = im_helpers._ctx(W, H).optimize_window(gray, [win])
+        if int(score[0]) == 0:
+            return (0.0, window)
+        x, y, w, h = (int(v) for v in out[0])
+        return (float(int(score[0]) // mult), utils.Rectangle.from_points((x, y), (x + w, y + h)))
 
     def is_homography_based(self) -> bool:
         return self.algorithm in [Detector.Algorithm.HOMOGRAPHY]

@@ -219,6 +219,50 @@ def main():
 
     np.savez_compressed(os.path.join(OUT, "foe_chain.npz"), **out)
     print("wrote", os.path.join(OUT, "foe_chain.npz"), {k: getattr(v, "shape", None) for k, v in out.items()})
+    window_search(ref_det, ref_im, ref_utils)
+
+
+def _blob_image(W, H, seed, blobs):
+    rng = np.random.default_rng(seed)
+    img = (rng.integers(0, 40, (H, W)) * (rng.random((H, W)) > 0.97)).astype(np.uint8)
+    yy, xx = np.mgrid[0:H, 0:W]
+    for (cx, cy, rad, amp) in blobs:
+        d2 = (xx - cx) ** 2 + (yy - cy) ** 2
+        img = np.maximum(img, (amp * np.exp(-d2 / (2.0 * rad * rad))).astype(np.uint8))
+    return img
+
+
+def window_search(ref_det, ref_im, ref_utils):
+    """Detector.optimize_window (detector.py:314-358) and the level-0 scan of analyze_pyramid (detector.py:296-310 on
+    im_helpers.sliding_window :38-52).  The upper pyramid levels need imutils / cv2 and cannot be generated here."""
+    out = {}
+    W, H = 200, 150
+    cases = [
+        ("mid", _blob_image(W, H, 11, [(120, 80, 9, 220)]), (88, 48, 64, 64)),
+        ("corner", _blob_image(W, H, 12, [(6, 5, 7, 200)]), (0, 0, 64, 64)),          # growth runs into the wrap-around of negative slices
+        ("edge", _blob_image(W, H, 13, [(192, 140, 10, 250), (60, 60, 5, 90)]), (136, 86, 64, 64)),
+        ("zero", np.zeros((H, W), np.uint8), (16, 16, 64, 64)),
+        ("small", _blob_image(W, H, 14, [(100, 75, 30, 255)]), (90, 70, 8, 8)),
+    ]
+    for tag, img, win in cases:
+        rgb = np.repeat(img[..., None], 3, axis=2)
+        score, rect = ref_det.Detector.optimize_window(None, rgb, ref_utils.Rectangle((win[0], win[1]), (win[2], win[3])))
+        out[f"opt_{tag}_img"] = img
+        out[f"opt_{tag}_in"] = np.array(win, np.int64)
+        out[f"opt_{tag}_out"] = np.array([score, rect.topleft[0], rect.topleft[1], rect.size[0], rect.size[1]], np.float64)
+        # level-0 scan: the loop body of analyze_pyramid on the reference's own sliding_window generator
+        best = (0, 0, 0, 0, 0)
+        for (x, y, window) in ref_im.sliding_window(rgb, stepSize=16, windowSize=(64, 64)):
+            if window.shape[0] != 64 or window.shape[1] != 64:
+                continue
+            s = np.sum(window)
+            am = np.unravel_index(window.argmax(), window.shape)
+            if best[0] < s:
+                best = (int(s), x, y, int(am[0]), int(am[1]))
+        out[f"scan_{tag}"] = np.array(best, np.int64)
+    out["cases"] = np.array([c[0] for c in cases])
+    np.savez_compressed(os.path.join(OUT, "window_search.npz"), **out)
+    print("wrote", os.path.join(OUT, "window_search.npz"))
 
 
 if __name__ == "__main__":
