@@ -79,7 +79,9 @@ __global__ __launch_bounds__(256) void k_blur_resize_h(const uint8_t* __restrict
         float prev[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) prev[k] = (float)rows[k][s0 - r];
-        for (int t = 0; t < bp.ksize; t++) {
+        // the taps of one thread are independent loads: with a compile-time count they are all in flight together (a
+        // runtime-count loop waits for memory once per tap); ksize 5 is the standard preset's coarse layer
+        auto taps = [&](int t) {
             const float g = bp.g[t];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -88,6 +90,13 @@ __global__ __launch_bounds__(256) void k_blur_resize_h(const uint8_t* __restrict
                 b1[k] += g * nxt;
                 prev[k] = nxt;
             }
+        };
+        if (bp.ksize == 5) {
+#pragma unroll
+            for (int t = 0; t < 5; t++) taps(t);
+        } else {
+#pragma unroll 8
+            for (int t = 0; t < bp.ksize; t++) taps(t);
         }
     } else {
         for (int t = 0; t < bp.ksize; t++) {
@@ -118,12 +127,19 @@ __global__ __launch_bounds__(256) void k_blur_resize_v(const float* __restrict__
     float b0 = 0.f, b1 = 0.f;
     if (s0 - r >= 0 && s0 + 1 + r < H) {
         float prev = src[(size_t)(s0 - r) * w];
-        for (int t = 0; t < bp.ksize; t++) {
+        auto tap = [&](int t) {
             const float g = bp.g[t];
             const float nxt = src[(size_t)(s0 - r + t + 1) * w];
             b0 += g * prev;
             b1 += g * nxt;
             prev = nxt;
+        };
+        if (bp.ksize == 5) {
+#pragma unroll
+            for (int t = 0; t < 5; t++) tap(t);
+        } else {
+#pragma unroll 8
+            for (int t = 0; t < bp.ksize; t++) tap(t);
         }
     } else {
         for (int t = 0; t < bp.ksize; t++) {
@@ -213,10 +229,29 @@ __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ I, si
     const int x0 = blockIdx.x * PX, y0 = blockIdx.y * PY;
     const float* src = I + (size_t)blockIdx.z * I_stride;
 
-    for (int i = tid; i < EX * EY; i += 256) {
-        const int ly = i / EX, lx = i - ly * EX;
-        const int gx = clampi(x0 - n + lx, 0, w - 1), gy = clampi(y0 - n + ly, 0, h - 1);
-        tile[i] = src[(size_t)gy * w + gx];
+    if constexpr (N_T > 0) {
+        // all of a thread's loads are issued before the first one is consumed (a load -> LDS-store loop would serialise
+        // ten memory round trips per workgroup)
+        constexpr int TOT = (PX + 2 * N_T) * (PY + 2 * N_T), CNT = (TOT + 255) / 256;
+        float v[CNT];
+#pragma unroll
+        for (int j = 0; j < CNT; j++) {
+            const int i = tid + 256 * j;
+            if (i < TOT) {
+                const int ly = i / EX, lx = i - ly * EX;
+                const int gx = clampi(x0 - n + lx, 0, w - 1), gy = clampi(y0 - n + ly, 0, h - 1);
+                v[j] = src[(size_t)gy * w + gx];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CNT; j++)
+            if (tid + 256 * j < TOT) tile[tid + 256 * j] = v[j];
+    } else {
+        for (int i = tid; i < EX * EY; i += 256) {
+            const int ly = i / EX, lx = i - ly * EX;
+            const int gx = clampi(x0 - n + lx, 0, w - 1), gy = clampi(y0 - n + ly, 0, h - 1);
+            tile[i] = src[(size_t)gy * w + gx];
+        }
     }
     __syncthreads();
     for (int i = tid; i < PY * EX; i += 256) {
@@ -263,6 +298,7 @@ __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ I, si
         dst[4 * npx + o] = b6 * pc.ig55;
     }
 }
+
 
 void launch_polyexp(hipStream_t st, const float* I, size_t I_stride, int G, int w, int h, const PolyCoef& pc, float* R,
                     size_t R_stride)

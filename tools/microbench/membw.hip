@@ -23,8 +23,42 @@ __global__ __launch_bounds__(256) void k_r3w1(const float4* __restrict__ a, cons
         d[i] = make_float4(x.x + y.x + z.x, x.y + y.y + z.y, x.z + y.z + z.z, x.w + y.w + z.w);
     }
 }
+// 1 read : 5 writes (the polynomial expansion: image in, five coefficient planes out) and write only
+__global__ __launch_bounds__(256) void k_r1w5(const float4* __restrict__ a, float4* __restrict__ o, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float4 x = a[i];
+        o[i] = x; o[n + i] = x; o[2 * n + i] = x; o[3 * n + i] = x; o[4 * n + i] = x;
+    }
+}
+__global__ __launch_bounds__(256) void k_write(float4* __restrict__ o, size_t n)
+{
+    const float4 x = make_float4(1.f, 2.f, 3.f, 4.f);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) o[i] = x;
+}
+static void write_mixes()
+{
+    const size_t sizes_mb[] = {8, 64, 512};                       // size of the input plane; the output is 5x that
+    for (size_t mb : sizes_mb) {
+        const size_t bytes = mb << 20, n = bytes / 16;
+        float4 *a, *o;
+        hipMalloc(&a, bytes); hipMalloc(&o, 5 * bytes);
+        hipMemset(a, 1, bytes);
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        const int reps = mb >= 512 ? 10 : 50, grid = 256 * 8;
+        float ms;
+        for (int w = 0; w < 3; w++) hipLaunchKernelGGL(k_r1w5, dim3(grid), dim3(256), 0, 0, a, o, n);
+        hipEventRecord(e0); for (int r = 0; r < reps; r++) hipLaunchKernelGGL(k_r1w5, dim3(grid), dim3(256), 0, 0, a, o, n); hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1); const double mix = 6.0 * bytes * reps / (ms * 1e-3) / 1e12;
+        hipEventRecord(e0); for (int r = 0; r < reps; r++) hipLaunchKernelGGL(k_write, dim3(grid), dim3(256), 0, 0, o, 5 * n); hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1); const double wr = 5.0 * bytes * reps / (ms * 1e-3) / 1e12;
+        printf("plane %4zu MB: 1r+5w %.2f TB/s (footprint %zu MB)   write only %.2f TB/s (footprint %zu MB)\n", mb, mix, 6 * mb, wr, 5 * mb);
+        hipFree(a); hipFree(o);
+    }
+}
 int main()
 {
+    write_mixes();
     const size_t sizes_mb[] = {16, 32, 64, 128, 512, 2048};
     float* out; hipMalloc(&out, 4);
     for (size_t mb : sizes_mb) {
