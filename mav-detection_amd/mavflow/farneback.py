@@ -21,18 +21,45 @@ def bgr_to_gray(img: np.ndarray) -> np.ndarray:
     return ((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14).astype(np.uint8)
 
 
+def flow_to_hsv(flow: np.ndarray):
+    """The HSV image the reference composes from a flow field (farneback.py:83-94), including its quirks: hue = angle / 2
+    in degrees truncated to u8, saturation 255, value = 2 x min-max-normalised magnitude stored into a u8 array (numpy
+    wraps it modulo 256, so the upper half of the magnitude range folds over), and pixels with value < 1 repainted as
+    (127, 255, 255).  cv2.cartToPolar's angle is a ~0.3 degree approximation, so hues can differ by one step from cv2's:
+    visualisation only, not a parity surface.  Returns (hsv u8, invalid_frame)."""
+    fx, fy = flow[..., 0].astype(np.float32), flow[..., 1].astype(np.float32)
+    mag = np.sqrt(fx * fx + fy * fy)
+    ang = np.arctan2(fy, fx).astype(np.float32)
+    ang = np.where(ang < 0, ang + np.float32(2 * np.pi), ang)
+    lo, hi = float(mag.min()), float(mag.max())
+    norm = np.zeros_like(mag) if hi - lo <= np.finfo(np.float64).eps else (mag - lo) * np.float32(255.0 / (hi - lo))
+    hsv = np.zeros(flow.shape[:2] + (3,), np.uint8)
+    hsv[..., 0] = (ang * 180 / np.pi / 2).astype(np.int64) & 255
+    hsv[..., 1] = 255
+    hsv[..., 2] = (norm * 2.0).astype(np.int64) & 255
+    mask = hsv[..., 2] < 1
+    hsv[mask, 0] = 127
+    hsv[mask, 2] = 255
+    return hsv, bool(np.sum((norm * 2.0).astype(np.int64) & 255) < 1)
+
+
+def hsv_to_bgr(hsv: np.ndarray) -> np.ndarray:
+    """cv2.cvtColor(COLOR_HSV2BGR) on u8 (H in [0, 180)): the float sector formula, rounded to nearest."""
+    h = hsv[..., 0].astype(np.float32) * np.float32(6.0 / 180.0)
+    s = hsv[..., 1].astype(np.float32) / np.float32(255)
+    v = hsv[..., 2].astype(np.float32) / np.float32(255)
+    sector = np.floor(h)
+    f = h - sector
+    sector = sector.astype(np.int64) % 6
+    tab = np.stack([v, v * (1 - s), v * (1 - s * f), v * (1 - s * (1 - f))], axis=-1)
+    idx = np.array([[1, 3, 0], [1, 0, 2], [3, 0, 1], [0, 2, 1], [0, 1, 3], [2, 1, 0]])   # (b, g, r) picks per sector
+    pick = idx[sector]
+    bgr = np.take_along_axis(tab, pick, axis=-1)
+    return np.clip(np.rint(bgr * 255.0), 0, 255).astype(np.uint8)
+
+
 def flow_to_bgr(flow: np.ndarray) -> np.ndarray:
-    """Direction -> hue, magnitude -> value (visualisation only; not a parity surface)."""
-    fx, fy = flow[..., 0].astype(np.float64), flow[..., 1].astype(np.float64)
-    mag = np.hypot(fx, fy)
-    ang = np.arctan2(fy, fx) % (2 * np.pi)
-    top = mag.max()
-    v = np.zeros_like(mag) if top <= 0 else np.clip(2.0 * 255 * mag / top, 0, 255)
-    h6 = ang / (np.pi / 3)
-    k = lambda n: (n + h6) % 6
-    chan = lambda n: v - v * np.clip(np.minimum(k(n), 4 - k(n)), 0, 1)
-    rgb = np.stack([chan(5), chan(3), chan(1)], axis=-1)
-    return np.rint(rgb[..., ::-1]).astype(np.uint8)
+    return hsv_to_bgr(flow_to_hsv(flow)[0])
 
 
 class Farneback:
@@ -60,9 +87,9 @@ class Farneback:
         gray = self._gray(img)
         self.flow = self.ctx.farneback(self.prevgray, gray)[0]
         self.prevgray = gray
-        result = flow_to_bgr(self.flow)
-        mag = np.hypot(self.flow[..., 0], self.flow[..., 1])
-        if mag.max() == mag.min():                     # "invalid frame" (min-max normalised magnitude sums to 0, :89): keep the previous result
+        self.hsv, invalid_frame = flow_to_hsv(self.flow)
+        result = hsv_to_bgr(self.hsv)
+        if invalid_frame:                              # the normalised magnitude sums to 0 (:89): keep the previous result (:97-98)
             result = self.prev_result
         self.prev_result = result
         return result
