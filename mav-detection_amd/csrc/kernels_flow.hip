@@ -95,8 +95,46 @@ __global__ __launch_bounds__(256) void k_blur_resize_h(const uint8_t* __restrict
 #pragma unroll
             for (int t = 0; t < 5; t++) taps(t);
         } else {
-#pragma unroll 8
-            for (int t = 0; t < bp.ksize; t++) taps(t);
+            // long kernels (the 4K / 5-layer preset has 13-, 37- and 95-tap layers): the ksize + 1 consecutive bytes of a row
+            // come as ALIGNED dwords and are re-aligned with v_alignbyte -- a quarter of the load instructions.  Only words
+            // that hold a needed byte are read (an aligned dword never crosses a page, so nothing unmapped is touched).
+            // Same products in the same order as the byte loop: identical results.
+            const uint32_t* wp[4];
+            unsigned sh[4];
+            uint32_t lo[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uintptr_t a = (uintptr_t)(rows[k] + (s0 - r));
+                wp[k] = (const uint32_t*)(a & ~(uintptr_t)3);
+                sh[k] = (unsigned)(a & 3);
+                lo[k] = wp[k][0];
+            }
+            const int nbytes = bp.ksize + 1;                 // byte 0 = prev, byte j = tap j - 1's "next"
+            for (int c = 0; 4 * c < nbytes; c++) {
+                uint32_t cur[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    // the needed bytes sit at positions sh .. sh + nbytes - 1 of the word stream
+                    const uint32_t hi = c + 1 <= ((int)sh[k] + nbytes - 1) / 4 ? wp[k][c + 1] : 0u;
+                    cur[k] = __builtin_amdgcn_alignbyte(hi, lo[k], sh[k]);
+                    lo[k] = hi;
+                }
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const int j = 4 * c + b;
+                    if (j >= nbytes) break;
+                    if (j > 0) {
+                        const float g = bp.g[j - 1];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const float nxt = (float)((cur[k] >> (8 * b)) & 0xffu);
+                            b0[k] += g * prev[k];
+                            b1[k] += g * nxt;
+                            prev[k] = nxt;
+                        }
+                    }
+                }
+            }
         }
     } else {
         for (int t = 0; t < bp.ksize; t++) {
