@@ -671,7 +671,10 @@ static __device__ __forceinline__ void update_finish(const float q[5], const Gat
     out[4] = r6 * r2 + r5 * r3;
 }
 
-template <int M_T>
+struct __attribute__((packed, aligned(4))) F2U { float x, y; };     // two adjacent floats at 4-byte alignment
+// AL = true: width a multiple of 4 and 16-byte aligned planes (vector loads / stores as written); AL = false: any width -- the
+// column pairs are read as two floats at 4-byte alignment and the flow is stored pixel by pixel.
+template <int M_T, bool AL = true>
 __global__ __launch_bounds__(256) void k_blur_iter_fast(const float* __restrict__ M_in, float* __restrict__ M_out,
                                                         size_t M_stride, const float* __restrict__ R0,
                                                         const float* __restrict__ R1, size_t R_stride, int w, int h,
@@ -723,8 +726,11 @@ __global__ __launch_bounds__(256) void k_blur_iter_fast(const float* __restrict_
             const float* col = Min + c * npx + (x0 - M_T + 2 * pr);
             float2 v[EXT_Y];
 #pragma unroll
-            for (int i = 0; i < EXT_Y; i++)
-                v[i] = *(const float2*)(col + (size_t)clampi(y0 - M_T + i, 0, h - 1) * w);
+            for (int i = 0; i < EXT_Y; i++) {
+                const float* pp = col + (size_t)clampi(y0 - M_T + i, 0, h - 1) * w;
+                if (AL) v[i] = *(const float2*)pp;
+                else { const F2U t = *(const F2U*)pp; v[i] = make_float2(t.x, t.y); }
+            }
             float* out = vs + c * PLANE + 2 * pr;
             float sx = 0.f, sy = 0.f;
 #pragma unroll
@@ -795,10 +801,16 @@ __global__ __launch_bounds__(256) void k_blur_iter_fast(const float* __restrict_
 #pragma unroll
         for (int j = 0; j < 4; j++)
             solve_px(S[0][j] * scale, S[1][j] * scale, S[2][j] * scale, S[3][j] * scale, S[4][j] * scale, &u[j], &v[j]);
-        if (store_flow && gx < w && gy < h) {            // w % 4 == 0: the 4 pixels are all inside or all outside
+        if (store_flow && gx < w && gy < h) {
             float* fo = flow + (size_t)s * f_stride + ((size_t)gy * w + gx) * 2;
-            *(float4*)fo = make_float4(u[0], v[0], u[1], v[1]);
-            *(float4*)(fo + 4) = make_float4(u[2], v[2], u[3], v[3]);
+            if (AL) {                                        // w % 4 == 0: the 4 pixels are all inside or all outside
+                *(float4*)fo = make_float4(u[0], v[0], u[1], v[1]);
+                *(float4*)(fo + 4) = make_float4(u[2], v[2], u[3], v[3]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (gx + j < w) *(float2*)(fo + 2 * j) = make_float2(u[j], v[j]);
+            }
         }
         if (!do_update) return;
         // park the flow in this wave's own rows of planes 0 (u) and 1 (v); every read of those rows by this wave is
@@ -1006,6 +1018,14 @@ void launch_blur_iter(hipStream_t st, const float* M_in, float* M_out, size_t M_
         const int per_img = tiles_x * tiles_y, n_tiles = per_img * G;
         const int nb = ((n_tiles + 7) / 8) * 8;        // the XCD-aware renumbering needs a multiple of 8 workgroups
         hipLaunchKernelGGL(k_blur_iter_fast<6>, dim3(nb), dim3(256), 0, st, M_in, M_out, M_stride, R0, R1, R_stride, w, h,
+                           tiles_x, per_img, n_tiles, scale, do_update, store_flow, flow, f_stride);
+        return;
+    }
+    if (m == 6 && f_stride % 2 == 0 && ((uintptr_t)flow & 7) == 0) {    // any width / alignment: relaxed form of the same kernel
+        const int tiles_x = (w + FT_X - 1) / FT_X, tiles_y = (h + FT_Y - 1) / FT_Y;
+        const int per_img = tiles_x * tiles_y, n_tiles = per_img * G;
+        const int nb = ((n_tiles + 7) / 8) * 8;
+        hipLaunchKernelGGL((k_blur_iter_fast<6, false>), dim3(nb), dim3(256), 0, st, M_in, M_out, M_stride, R0, R1, R_stride, w, h,
                            tiles_x, per_img, n_tiles, scale, do_update, store_flow, flow, f_stride);
         return;
     }

@@ -14,7 +14,7 @@ for case in range(n_cases):
     if case % 3 == 0:
         W, H = int(rng.integers(8, 64)) * 4, int(rng.integers(33, 200))          # fast-path widths (multiples of 4)
     elif case % 3 == 1:
-        W, H = int(rng.integers(33, 300)), int(rng.integers(33, 200))            # arbitrary widths (generic kernels)
+        W, H = int(rng.integers(33, 300)), int(rng.integers(33, 200))            # arbitrary widths (relaxed-alignment kernels)
     else:
         W, H = int(rng.choice([64, 128, 192, 256, 320, 704])), int(rng.choice([48, 64, 96, 160, 208]))
     fb = _lib.fb_defaults()
