@@ -500,6 +500,10 @@ static int farneback_group(mav_ctx* c, const uint8_t* prev, const uint8_t* next,
         const Layer& l = c->layers[k];
         const uint8_t* img[2] = {prev, next};
         float* R[2] = {c->R0, c->R1};
+        // The finest layer's ten sweeps re-read R0/R1 (and M or the flow): run them `group_fine` pairs at a time so that
+        // one sub-group's working set stays resident in the 256 MB Infinity Cache between sweeps.  Coarse layers are
+        // small: all g pairs per launch to fill the 256 CUs.
+        const int sub = (k == 0 && c->group_fine > 0 && c->group_fine < g) ? c->group_fine : g;
         for (int i = 0; i < 2; i++) {
             { ProfScope ps(c, K_BLUR_RESIZE);
               launch_blur_resize(c->stream, img[i], n0, g, c->W, c->H, l.w, l.h, blur_of(c, l), c->Htmp, c->htmp_stride, c->I, n0); }
@@ -508,10 +512,6 @@ static int farneback_group(mav_ctx* c, const uint8_t* prev, const uint8_t* next,
         }
         float* fdst = k > 0 ? c->fc[k & 1] : flow_out;
         const size_t fstride = k > 0 ? fc_stride : 2 * n0;
-        // The finest layer's ten sweeps re-read R0/R1 (and M or the flow): run them `group_fine` pairs at a time so that
-        // one sub-group's working set stays resident in the 256 MB Infinity Cache between sweeps.  Coarse layers are
-        // small: all g pairs per launch to fill the 256 CUs.
-        const int sub = (k == 0 && c->group_fine > 0 && c->group_fine < g) ? c->group_fine : g;
         const float mul = (float)(1. / c->fb.pyr_scale);
         // Optional form ("recompute"): sweeps that rebuild M from (R0, R1, flow) on the fly -- no M arrays, no initial-M
         // kernel, 56 instead of 80 B/px of HBM traffic; the flow ping-pongs between the (otherwise unused) Ma / Mb buffers.
@@ -538,10 +538,22 @@ static int farneback_group(mav_ctx* c, const uint8_t* prev, const uint8_t* next,
             }
         }
         if (!rc_ok) {
-            { ProfScope ps(c, K_UPDATE);
-              launch_update_matrices(c->stream, c->R0, c->R1, 5 * n0, flow_prev, fc_stride, pw, ph, mul, g, l.w, l.h, c->Ma, 5 * n0); }
+            // with per-sub-group sweeps the initial M of a sub-group is built right before its sweeps: M, R0 and R1 are then
+            // still in the Infinity Cache when the first sweep reads them (measured -0.5 ms per 64 pairs; doing the same with the
+            // blur and the expansion costs more in small launches than it returns)
+            const bool m_per_sub = sub < g;
+            if (!m_per_sub) {
+                ProfScope ps(c, K_UPDATE);
+                launch_update_matrices(c->stream, c->R0, c->R1, 5 * n0, flow_prev, fc_stride, pw, ph, mul, g, l.w, l.h, c->Ma, 5 * n0);
+            }
             for (int s0 = 0; s0 < g; s0 += sub) {
                 const int gs = g - s0 < sub ? g - s0 : sub;
+                if (m_per_sub) {
+                    ProfScope ps(c, K_UPDATE);
+                    launch_update_matrices(c->stream, c->R0 + (size_t)s0 * 5 * n0, c->R1 + (size_t)s0 * 5 * n0, 5 * n0,
+                                           flow_prev ? flow_prev + (size_t)s0 * fc_stride : nullptr, fc_stride, pw, ph, mul, gs, l.w, l.h,
+                                           c->Ma + (size_t)s0 * 5 * n0, 5 * n0);
+                }
                 float *Min = c->Ma + (size_t)s0 * 5 * n0, *Mout = c->Mb + (size_t)s0 * 5 * n0;
                 for (int it = 0; it < c->fb.iterations; it++) {
                     const int upd = it < c->fb.iterations - 1;
