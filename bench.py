@@ -64,6 +64,18 @@ def cpu_baseline(prev, nxt, samples, n_sample, gpu_flow_fn=None):
     out = {"value": n_sample / dt, "unit": "frame-pairs/s", "cores": 1, "kind": kind,
            "sample": f"{n_sample} of the benchmark's {prev.shape[2]}x{prev.shape[1]} pairs, {label} + numpy FoE chain, {dt:.1f} s, "
                      f"host has {os.cpu_count()} cores"}
+    # the same sample once more, frame-parallel over this GPU's share of the host cores (threads: the C flow call releases the GIL)
+    nthr = max(1, min(16, os.cpu_count() or 1, n_sample))
+    if nthr > 1:
+        from concurrent.futures import ThreadPoolExecutor
+
+        def one(b):
+            foe_oracle.run_chain(flow_fn(prev[b], nxt[b]), samples[b])
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(nthr) as ex:
+            list(ex.map(one, range(n_sample)))
+        dtp = time.perf_counter() - t0
+        out["frame_parallel"] = {"value": n_sample / dtp, "unit": "frame-pairs/s", "cores": nthr, "seconds": round(dtp, 2)}
     if gpu_flow_fn is not None and flows:          # the metric's second half: end-point error of the GPU flow against the CPU flow
         g = gpu_flow_fn(prev[:len(flows)], nxt[:len(flows)])
         e = np.concatenate([np.hypot(g[i][..., 0] - f[..., 0], g[i][..., 1] - f[..., 1]).ravel() for i, f in enumerate(flows)])
