@@ -77,24 +77,24 @@ __global__ __launch_bounds__(256) void k_blur_resize_h(const uint8_t* __restrict
     float b0[4] = {0.f, 0.f, 0.f, 0.f}, b1[4] = {0.f, 0.f, 0.f, 0.f};
     if (s0 - r >= 0 && s0 + 1 + r < W) {               // interior: B[s0+1] re-uses B[s0]'s pixels shifted by one
         float prev[4];
+        if (bp.ksize == 5) {                               // all 24 bytes of the thread requested before any is used
+            uint8_t px[4][6];
 #pragma unroll
-        for (int k = 0; k < 4; k++) prev[k] = (float)rows[k][s0 - r];
-        // the taps of one thread are independent loads: with a compile-time count they are all in flight together (a
-        // runtime-count loop waits for memory once per tap); ksize 5 is the standard preset's coarse layer
-        auto taps = [&](int t) {
-            const float g = bp.g[t];
+            for (int k = 0; k < 4; k++)
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const float nxt = (float)rows[k][s0 - r + t + 1];
-                b0[k] += g * prev[k];
-                b1[k] += g * nxt;
-                prev[k] = nxt;
+                for (int t = 0; t < 6; t++) px[k][t] = rows[k][s0 - 2 + t];
+#pragma unroll
+            for (int t = 0; t < 5; t++) {
+                const float g = bp.g[t];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    b0[k] += g * (float)px[k][t];
+                    b1[k] += g * (float)px[k][t + 1];
+                }
             }
-        };
-        if (bp.ksize == 5) {
-#pragma unroll
-            for (int t = 0; t < 5; t++) taps(t);
         } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) prev[k] = (float)rows[k][s0 - r];
             // long kernels (the 4K / 5-layer preset has 13-, 37- and 95-tap layers): the ksize + 1 consecutive bytes of a row
             // come as ALIGNED dwords and are re-aligned with v_alignbyte -- a quarter of the load instructions.  Only words
             // that hold a needed byte are read (an aligned dword never crosses a page, so nothing unmapped is touched).
@@ -164,20 +164,22 @@ __global__ __launch_bounds__(256) void k_blur_resize_v(const float* __restrict__
     const int s1 = s0 + 1 < H ? s0 + 1 : s0;
     float b0 = 0.f, b1 = 0.f;
     if (s0 - r >= 0 && s0 + 1 + r < H) {
-        float prev = src[(size_t)(s0 - r) * w];
-        auto tap = [&](int t) {
-            const float g = bp.g[t];
-            const float nxt = src[(size_t)(s0 - r + t + 1) * w];
-            b0 += g * prev;
-            b1 += g * nxt;
-            prev = nxt;
-        };
-        if (bp.ksize == 5) {
+        if (bp.ksize == 5) {                               // the six rows of the thread requested together
+            float px[6];
 #pragma unroll
-            for (int t = 0; t < 5; t++) tap(t);
+            for (int t = 0; t < 6; t++) px[t] = src[(size_t)(s0 - 2 + t) * w];
+#pragma unroll
+            for (int t = 0; t < 5; t++) { b0 += bp.g[t] * px[t]; b1 += bp.g[t] * px[t + 1]; }
         } else {
+            float prev = src[(size_t)(s0 - r) * w];
 #pragma unroll 8
-            for (int t = 0; t < bp.ksize; t++) tap(t);
+            for (int t = 0; t < bp.ksize; t++) {
+                const float g = bp.g[t];
+                const float nxt = src[(size_t)(s0 - r + t + 1) * w];
+                b0 += g * prev;
+                b1 += g * nxt;
+                prev = nxt;
+            }
         }
     } else {
         for (int t = 0; t < bp.ksize; t++) {
