@@ -204,16 +204,26 @@ __global__ __launch_bounds__(256) void k_blur3_u8(const uint8_t* __restrict__ im
     float* dst = out + (size_t)blockIdx.z * out_stride;
     const int xl = x == 0 ? 1 : x - 1;                    // reflect101
     const int xr = x + 4 >= W ? W - 2 : x + 4;
-    float hrow[6][4];
+    // all 18 loads of the thread first (six rows x {left byte, aligned dword, right byte}); the outputs below are computed
+    // unconditionally and only the stores are predicated, so no load is deferred behind a branch
+    uint32_t qs[6];
+    uint8_t ls[6], rs[6];
 #pragma unroll
     for (int r = 0; r < 6; r++) {
         int yy = y0 - 1 + r;
         yy = yy < 0 ? -yy : (yy >= H ? 2 * H - 2 - yy : yy);
         yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);         // rows past the image (tail of the last group): any valid row
         const uint8_t* p = src + (size_t)yy * W;
-        const uint32_t q = *(const uint32_t*)(p + x);
-        const float a = (float)p[xl], b0 = (float)(q & 255u), b1 = (float)((q >> 8) & 255u), b2 = (float)((q >> 16) & 255u),
-                    b3 = (float)(q >> 24), c = (float)p[xr];
+        qs[r] = *(const uint32_t*)(p + x);
+        ls[r] = p[xl];
+        rs[r] = p[xr];
+    }
+    float hrow[6][4];
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        const uint32_t q = qs[r];
+        const float a = (float)ls[r], b0 = (float)(q & 255u), b1 = (float)((q >> 8) & 255u), b2 = (float)((q >> 16) & 255u),
+                    b3 = (float)(q >> 24), c = (float)rs[r];
         hrow[r][0] = 0.5f * b0 + 0.25f * (a + b1);
         hrow[r][1] = 0.5f * b1 + 0.25f * (b0 + b2);
         hrow[r][2] = 0.5f * b2 + 0.25f * (b1 + b3);
@@ -221,13 +231,12 @@ __global__ __launch_bounds__(256) void k_blur3_u8(const uint8_t* __restrict__ im
     }
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        if (y0 + r >= H) break;
         float4 o;
         o.x = 0.5f * hrow[r + 1][0] + 0.25f * (hrow[r][0] + hrow[r + 2][0]);
         o.y = 0.5f * hrow[r + 1][1] + 0.25f * (hrow[r][1] + hrow[r + 2][1]);
         o.z = 0.5f * hrow[r + 1][2] + 0.25f * (hrow[r][2] + hrow[r + 2][2]);
         o.w = 0.5f * hrow[r + 1][3] + 0.25f * (hrow[r][3] + hrow[r + 2][3]);
-        *(float4*)(dst + (size_t)(y0 + r) * W + x) = o;
+        if (y0 + r < H) *(float4*)(dst + (size_t)(y0 + r) * W + x) = o;
     }
 }
 
