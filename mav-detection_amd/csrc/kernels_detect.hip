@@ -15,10 +15,9 @@
 #include <stdlib.h>
 
 // Derotated flow vector at pixel (col, row) in double, reference operation order (detector.py:92-114).
-static __device__ __forceinline__ void flow_at(const float* __restrict__ flow, const DerotParams* __restrict__ dp, int W, int H,
-                                               int row, int col, double* fu, double* fv)
+static __device__ __forceinline__ void derot_apply(float2 f, const DerotParams* __restrict__ dp, int W, int H, int row, int col,
+                                                   double* fu, double* fv)
 {
-    const float2 f = *(const float2*)(flow + ((size_t)row * W + col) * 2);
     double u = (double)f.x, v = (double)f.y;
     if (dp && dp->enabled) {
         const double x = -((double)col / (double)W - 0.5) * 2.0;
@@ -33,11 +32,23 @@ static __device__ __forceinline__ void flow_at(const float* __restrict__ flow, c
     }
     *fu = u; *fv = v;
 }
-static __device__ __forceinline__ void flow_at(const double* __restrict__ flow, const DerotParams*, int W, int H, int row, int col,
-                                               double* fu, double* fv)
+static __device__ __forceinline__ void derot_apply(double2 f, const DerotParams*, int, int, int, int, double* fu, double* fv)
 {
-    const double2 f = *(const double2*)(flow + ((size_t)row * W + col) * 2);
     *fu = f.x; *fv = f.y;
+}
+static __device__ __forceinline__ float2 flow_raw(const float* __restrict__ flow, int W, int row, int col)
+{
+    return *(const float2*)(flow + ((size_t)row * W + col) * 2);
+}
+static __device__ __forceinline__ double2 flow_raw(const double* __restrict__ flow, int W, int row, int col)
+{
+    return *(const double2*)(flow + ((size_t)row * W + col) * 2);
+}
+template <typename FlowT>
+static __device__ __forceinline__ void flow_at(const FlowT* __restrict__ flow, const DerotParams* __restrict__ dp, int W, int H,
+                                               int row, int col, double* fu, double* fv)
+{
+    derot_apply(flow_raw(flow, W, row, col), dp, W, H, row, col, fu, fv);
 }
 
 __global__ __launch_bounds__(256) void k_derotate(const float* __restrict__ flow, const DerotParams* __restrict__ derot, int W,
@@ -314,22 +325,36 @@ __global__ __launch_bounds__(256) void k_phi_mask(const FlowT* __restrict__ flow
     int bx0 = INT_MAX, by0 = INT_MAX, bx1 = -1, by1 = -1;
     double pmax = 0.0;
     const int xb = (blockIdx.x * 64 + lane) * VEC;
+    const bool colok = xb < W;                            // lanes past the right edge stay for the wave reductions below
+    const int xld = colok ? xb : 0;
+    // every flow vector and sky word of the thread is requested before the first pixel is evaluated: the per-pixel code
+    // branches (exact path inside the guard bands), and loads left between those branches would be one round trip each
+    decltype(flow_raw(fl, W, 0, 0)) raw[4][VEC];
+    uint32_t skw[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int yc = min(blockIdx.y * 16 + wv * 4 + r, H - 1);          // rows past the bottom: re-read the last row, never stored
+#pragma unroll
+        for (int j = 0; j < VEC; j++) raw[r][j] = flow_raw(fl, W, yc, xld + j);
+        const size_t oc = b * npx + (size_t)yc * W + xld;
+        skw[r] = !sky ? 0u : (VEC == 4 ? *(const uint32_t*)(sky + oc) : (uint32_t)sky[oc]);
+    }
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int y = blockIdx.y * 16 + wv * 4 + r;
-        if (y >= H || xb >= W) continue;
+        if (y >= H || !colok) continue;
         const size_t o = b * npx + (size_t)y * W + xb;
         uint8_t sk[VEC], mf[VEC], md[VEC];
         if (VEC == 4) {
-            const uint32_t s4 = sky ? *(const uint32_t*)(sky + o) : 0u;
+            const uint32_t s4 = skw[r];
             sk[0] = s4 & 255u; sk[1 % VEC] = (s4 >> 8) & 255u; sk[2 % VEC] = (s4 >> 16) & 255u; sk[3 % VEC] = s4 >> 24;
         } else
-            sk[0] = sky ? sky[o] : 0;
+            sk[0] = (uint8_t)skw[r];
 #pragma unroll
         for (int j = 0; j < VEC; j++) {
             const int x = xb + j;
             double u, v;
-            flow_at(fl, dp, W, H, y, x, &u, &v);
+            derot_apply(raw[r][j], dp, W, H, y, x, &u, &v);
             bool fix, dyn, have;
             double ph = 0.0;
             phi_pixel(u, v, x, y, foex, foey, sk[j] == 0, thr, scr, &fix, &dyn, &ph, &have);
