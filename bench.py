@@ -6,9 +6,14 @@
 A step is one pass of the whole path over one batch of synthetic 1920x1080 pairs (BASELINE config 3: batch 64 per
 GPU) with the frames already resident in HBM.  Prints ONE JSON line (rank 0).  Multi-GPU: every rank runs its own
 batch (weak scaling, no data-path collective) and the per-pair 32-byte result records are all-gathered over
-RCCL/xGMI at the end of each step, inside the timed region.
+RCCL/xGMI at the end of each step, inside the timed region, on the context's own stream (mav_allgather_results).
+
+After the timed loop, outside the timed region, the outputs the LAST timed step left behind are checked against the
+oracle (records, both masks and boxes bit for bit against the numpy chain evaluated on that step's own flow; that flow
+against the CPU Farneback): `verified_pairs`.  A mismatch makes the process exit non-zero.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -22,6 +27,7 @@ for p in (ROOT, os.path.join(ROOT, "mav-detection_amd")):
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
 ITER_BYTES_UPDATE = 88           # per pixel per sweep: read M 20 + R0 20 + R1 20, write M' 20 + flow 8   
 ITER_BYTES_LAST = 28             # last sweep of a layer: read M 20, write flow 8
+PROFILE_ROUND = "r02"
 
 
 def b_alg_per_pair(layers, W, H, iters):
@@ -37,66 +43,124 @@ def b_alg_per_pair(layers, W, H, iters):
     return tot + 10 * P0
 
 
-def cpu_baseline(prev, nxt, samples, n_sample, gpu_flow_fn=None):
-    """The CPU path on a bounded sample of the same workload, timed on this node's host cores (1 thread).
-    Preferred: cv2.calcOpticalFlowFarneback (kind "reference") when OpenCV is importable on the node; otherwise the oracle's C
-    restatement (kind "port", labelled as such).  The numpy FoE chain follows either."""
-    import numpy as np
-    from oracle import foe_oracle
+def source_hash():
+    """Identity of the kernel build: sha256 over the library's sources (the GPU box has no .git)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "mav-detection_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".cpp", ".h")) or name == "Makefile":
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def usable_cores():
+    """Host cores this process may actually run on: the affinity mask, capped by a cgroup CPU quota if there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_flow_fn():
+    """cv2.calcOpticalFlowFarneback when OpenCV is importable on the node (kind "reference"), else the oracle's C restatement
+    (kind "port", labelled as such)."""
     try:
         import cv2
         cv2.setNumThreads(1)
-        flow_fn = lambda a, b: cv2.calcOpticalFlowFarneback(a, b, None, 0.4, 1, 12, 10, 8, 1.2, 0)
-        kind, label = "reference", f"cv2 {cv2.__version__} calcOpticalFlowFarneback (1 thread)"
+        return (lambda a, b: cv2.calcOpticalFlowFarneback(a, b, None, 0.4, 1, 12, 10, 8, 1.2, 0)), "reference", \
+            f"cv2 {cv2.__version__} calcOpticalFlowFarneback (1 thread per pair)"
     except ImportError:
         from oracle import fb_oracle
-        orc = fb_oracle.load()
-        flow_fn = orc.calc
-        kind, label = "port", "oracle/farneback_oracle.c (restatement, not OpenCV: cv2 is not importable on this node)"
-    t0 = time.perf_counter()
-    flows = []
-    for b in range(n_sample):
-        flow = flow_fn(prev[b], nxt[b])
-        foe_oracle.run_chain(flow, samples[b])
-        if b < 2:
-            flows.append(flow)
-    dt = time.perf_counter() - t0
-    out = {"value": n_sample / dt, "unit": "frame-pairs/s", "cores": 1, "kind": kind,
-           "sample": f"{n_sample} of the benchmark's {prev.shape[2]}x{prev.shape[1]} pairs, {label} + numpy FoE chain, {dt:.1f} s, "
-                     f"host has {os.cpu_count()} cores"}
-    # the same sample once more, frame-parallel over this GPU's share of the host cores (threads: the C flow call releases the GIL)
-    nthr = max(1, min(16, os.cpu_count() or 1, n_sample))
-    if nthr > 1:
-        from concurrent.futures import ThreadPoolExecutor
+        return fb_oracle.load().calc, "port", "oracle/farneback_oracle.c (restatement, not OpenCV: cv2 is not importable on this node)"
 
-        def one(b):
-            foe_oracle.run_chain(flow_fn(prev[b], nxt[b]), samples[b])
+
+def cpu_baseline(prev, nxt, samples, n_sample, levels):
+    """The CPU path on a bounded sample of the same workload, timed on this node's host cores: once on ONE core, and once
+    frame-parallel on every core this process may use.  The numpy FoE chain follows the flow in both."""
+    from oracle import foe_oracle
+    flow_fn, kind, label = cpu_flow_fn()
+    if levels != 1:
+        from oracle import fb_oracle
+        orc, par = fb_oracle.load(), fb_oracle.default_params(levels)
+        flow_fn, kind, label = (lambda a, b: orc.calc(a, b, par)), "port", f"oracle/farneback_oracle.c, levels={levels} (restatement, not OpenCV)"
+    B = prev.shape[0]
+    t0 = time.perf_counter()
+    for b in range(n_sample):
+        foe_oracle.run_chain(flow_fn(prev[b % B], nxt[b % B]), samples[b % B])
+    dt = time.perf_counter() - t0
+    cores = usable_cores()
+    out = {"value": n_sample / dt, "unit": "frame-pairs/s", "cores": 1, "kind": kind,
+           "sample": f"{n_sample} of the benchmark's {prev.shape[2]}x{prev.shape[1]} pairs, {label} + numpy FoE chain, {dt:.1f} s on one core; "
+                     f"host has {os.cpu_count()} cores, {cores} usable by this process"}
+    if cores > 1:
+        # frame-parallel over all usable cores (threads: the C flow call and numpy's inner loops release the GIL); every
+        # thread gets the same number of pairs, at least as many pairs as cores
+        from concurrent.futures import ThreadPoolExecutor
+        per = max(1, min(8, int(10.0 / max(dt / n_sample, 1e-3))))       # about 10 s of work per core
+        n_all = cores * per
+
+        def one(i):
+            foe_oracle.run_chain(flow_fn(prev[i % B], nxt[i % B]), samples[i % B])
         t0 = time.perf_counter()
-        with ThreadPoolExecutor(nthr) as ex:
-            list(ex.map(one, range(n_sample)))
+        with ThreadPoolExecutor(cores) as ex:
+            list(ex.map(one, range(n_all)))
         dtp = time.perf_counter() - t0
-        out["frame_parallel"] = {"value": n_sample / dtp, "unit": "frame-pairs/s", "cores": nthr, "seconds": round(dtp, 2)}
-    if gpu_flow_fn is not None and flows:          # the metric's second half: end-point error of the GPU flow against the CPU flow
-        g = gpu_flow_fn(prev[:len(flows)], nxt[:len(flows)])
-        e = np.concatenate([np.hypot(g[i][..., 0] - f[..., 0], g[i][..., 1] - f[..., 1]).ravel() for i, f in enumerate(flows)])
-        out["flow_epe_px"] = {"mean": float(e.mean()), "p99.9": float(np.percentile(e, 99.9)), "max": float(e.max()),
-                              "against": "cv2" if kind == "reference" else "oracle restatement (cv2 absent)", "pairs": len(flows)}
+        out["all_cores"] = {"value": n_all / dtp, "unit": "frame-pairs/s", "cores": cores, "host_cores": os.cpu_count(),
+                            "pairs": n_all, "seconds": round(dtp, 2), "kind": kind}
     return out
+
+
+def verify_last_step(ctx, prev, nxt, samples, res, mf_buf, md_buf, pairs, levels):
+    """Outside the timed region: the records / masks / flow the last timed step left on the device, against the oracle."""
+    import numpy as np
+    from oracle import foe_oracle
+    flow_fn, kind, _ = cpu_flow_fn()
+    if levels != 1:
+        from oracle import fb_oracle
+        orc, par = fb_oracle.load(), fb_oracle.default_params(levels)
+        flow_fn, kind = (lambda a, b: orc.calc(a, b, par)), "port"
+    H, W = prev.shape[1:]
+    ok, bad, epes = [], [], []
+    for b in pairs:
+        flow = ctx.last_flow(b)
+        chain = foe_oracle.run_chain(flow, samples[b])
+        mf = np.empty((H, W), np.uint8)
+        md = np.empty((H, W), np.uint8)
+        ctx.lib.mav_memcpy_d2h(ctx.h, mf.ctypes.data, mf_buf.ptr + b * W * H, W * H)
+        ctx.lib.mav_memcpy_d2h(ctx.h, md.ctypes.data, md_buf.ptr + b * W * H, W * H)
+        e = np.hypot(*np.moveaxis(flow - flow_fn(prev[b], nxt[b]), -1, 0))
+        epes.append(e.ravel())
+        good = (tuple(res[b]["foe"]) == tuple(chain["foe"]) and tuple(res[b]["box"]) == tuple(chain["box"])
+                and np.array_equal(mf.view(np.bool_), chain["fixed"]) and np.array_equal(md.view(np.bool_), chain["total"])
+                and e.mean() <= 1e-2 and np.percentile(e, 99.9) <= 1e-1)
+        (ok if good else bad).append(int(b))
+    e = np.concatenate(epes)
+    return {"verified_pairs": ok, "failed_pairs": bad,
+            "checked": "records (FoE, box) and both masks of the last timed step bit-exact vs the numpy chain on that step's own flow; "
+                       "flow EPE vs the CPU Farneback within mean 1e-2 / p99.9 1e-1 px",
+            "flow_epe_px": {"mean": float(e.mean()), "p99.9": float(np.percentile(e, 99.9)), "max": float(e.max()),
+                            "against": "cv2" if kind == "reference" else "oracle restatement (cv2 absent)", "pairs": len(pairs)}}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=200, help="timed steps (200 x 28 ms: the GPU phase lasts > 5 s)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="pairs per GPU per step")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--levels", type=int, default=1, help="Farneback levels (BASELINE config 5 uses 5 at 3840x2160)")
     ap.add_argument("--group", type=int, default=0, help="pairs per launch (0 = library default)")
     ap.add_argument("--group-fine", type=int, default=-1, help="pairs per launch for the finest layer's sweeps (-1 = library default)")
-    ap.add_argument("--cpu-pairs", type=int, default=16, help="pairs in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-pairs", type=int, default=16, help="pairs in the one-core CPU baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -144,28 +208,45 @@ def main():
     d_next = ctx.alloc(nxt.nbytes).upload(nxt)
     d_smp = ctx.alloc(samples.nbytes).upload(samples)
     rec = _lib.RESULT_DTYPE.itemsize
-    if dist is not None:
-        t_local = torch.empty(B * rec, dtype=torch.uint8, device="cuda")
-        t_all = torch.empty(world * B * rec, dtype=torch.uint8, device="cuda")
-        res_ptr = t_local.data_ptr()
-    else:
-        d_res = ctx.alloc(B * rec)
-        res_ptr = d_res.ptr
-
+    d_res = ctx.alloc(B * rec)                         # this rank's records
+    d_all = ctx.alloc(world * B * rec) if dist is not None else None
     d_mf = ctx.alloc(B * W * H)
     d_md = ctx.alloc(B * W * H)
+
+    # the record exchange: RCCL all-gather on the CONTEXT's stream (mav_allgather_results), no host synchronisation inside a step.
+    # The 128-byte ncclUniqueId travels over the process group torch.distributed.run set up.  If the library cannot open its own
+    # communicator the bench falls back to torch's all_gather (two host syncs per step) and says so.
+    comm, exchange = None, "none (1 GPU)"
+    t_local = t_all = None
+    if dist is not None:
+        try:
+            uid = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                uid = torch.from_numpy(ctx.comm_unique_id().copy())
+            uid = uid.cuda()
+            dist.broadcast(uid, src=0)
+            comm = ctx.comm_init(uid.cpu().numpy(), rank, world)
+            exchange = "mav_allgather_results (RCCL ncclAllGather on the context's stream)"
+        except Exception as e:                         # noqa: BLE001 -- any failure here must not lose the measurement
+            comm, exchange = None, f"torch.distributed.all_gather_into_tensor (library communicator unavailable: {e})"
+            t_local = torch.empty(B * rec, dtype=torch.uint8, device="cuda")
+            t_all = torch.empty(world * B * rec, dtype=torch.uint8, device="cuda")
 
     def run_batch():
         # flow stays in the library's HBM workspace (flow_ptr=None); both threshold masks are written out (1 B/px each),
         # the per-pair box + FoE records are the result
-        ctx.process_batch_dev(d_prev.ptr, d_next.ptr, d_smp.ptr, B, res_ptr, mf_ptr=d_mf.ptr, md_ptr=d_md.ptr)
+        ctx.process_batch_dev(d_prev.ptr, d_next.ptr, d_smp.ptr, B, d_res.ptr, mf_ptr=d_mf.ptr, md_ptr=d_md.ptr)
 
     def step():
         run_batch()
-        if dist is not None:
-            ctx.sync()                                   # records are complete before the collective reads them
+        if comm is not None:
+            ctx.allgather(comm, d_res.ptr, B * rec, d_all.ptr)      # stream-ordered behind the batch, ahead of the next one
+        elif dist is not None:
+            ctx.sync()                                                 # (torch fallback) records -> torch tensor -> all_gather
+            torch.cuda.synchronize()
+            t_local.copy_(torch.from_numpy(d_res.download(np.uint8, (B * rec,))))
             mdist.allgather_records(dist, t_local, t_all)
-            torch.cuda.synchronize()                     # ... and gathered before the next step overwrites them
+            torch.cuda.synchronize()
 
     def barrier():
         ctx.sync()
@@ -189,6 +270,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- what did the timed loop compute?  (outside the timed region) ----
+    verification = None
+    res_last = d_res.download(_lib.RESULT_DTYPE, (B,))
+    if comm is not None:                               # the gathered block of this rank must be its own records
+        allrec = d_all.download(_lib.RESULT_DTYPE, (world * B,))
+        assert allrec[rank * B:(rank + 1) * B].tobytes() == res_last.tobytes(), "all-gathered records differ from the local ones"
+    if rank == 0 and not args.no_verify:
+        verification = verify_last_step(ctx, prev, nxt, samples, res_last, d_mf, d_md, sorted({0, B - 1}), args.levels)
+
     # ---- PCIe-inclusive rates (never `value`).  (1) naive: the two u8 frame stacks uploaded synchronously from pageable memory
     #      inside the loop; (2) pipelined: pinned memory, uploads on the context's copy stream into a second buffer set while
     #      the previous batch computes (how a deployment would feed the GPU) ----
@@ -209,8 +299,8 @@ def main():
         t1 = time.perf_counter()
         for k in range(n_pipe):
             cur, nx = sets[k & 1], sets[(k + 1) & 1]
-            ctx.upload_async(nx[0], hp); ctx.upload_async(nx[1], hn)              # next batch crosses PCIe now ...
-            ctx.process_batch_dev(cur[0].ptr, cur[1].ptr, d_smp.ptr, B, res_ptr, mf_ptr=d_mf.ptr, md_ptr=d_md.ptr)   # ... while this one computes
+            ctx.upload_async(nx[0], hp); ctx.upload_async(nx[1], hn)              # next batch crosses PCIe now (behind batch k-1) ...
+            ctx.process_batch_dev(cur[0].ptr, cur[1].ptr, d_smp.ptr, B, d_res.ptr, mf_ptr=d_mf.ptr, md_ptr=d_md.ptr)   # ... while this one computes
             ctx.upload_fence()
         ctx.sync()
         h2d_pipe_ms = 1e3 * (time.perf_counter() - t1) / n_pipe
@@ -227,20 +317,28 @@ def main():
         iters = ctx.fb.iterations
         bytes_step = B * sum(w * h * ((iters - 1) * ITER_BYTES_UPDATE + ITER_BYTES_LAST) for (w, h) in layers)
         achieved = bytes_step / (ms * 1e-3) / 1e9
-        # HBM bytes from the PMC counters (collected by tools/pmc_passes.sh in separate rocprofv3 --pmc runs, corrected as the
-        # microarchitecture guide prescribes, committed under profiles/): per launch, like `achieved`.  null when not measured
-        # for this workload shape.
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "r01", "traffic.json")
-        if os.path.exists(tj) and (W, H) == (1920, 1080) and ctx.fb.iterations == 10 and len(layers) == 2:
-            traffic = int(json.load(open(tj))["hbm_bytes_per_pair"] * B / max(launches, 1))
+        # HBM bytes from the PMC counters: collected by tools/pmc_passes.sh in separate rocprofv3 --pmc runs of THIS command,
+        # corrected as the microarchitecture guide prescribes, committed under profiles/ with the hash of the sources they were
+        # measured on.  Per launch, like `achieved`.  null unless the record matches this build, frame size, batch and schedule.
+        traffic, traffic_source = None, None
+        tj = os.path.join(ROOT, "profiles", PROFILE_ROUND, "traffic.json")
+        if os.path.exists(tj):
+            rec_t = json.load(open(tj))
+            want = {"source_hash": source_hash(), "width": W, "height": H, "batch": B, "levels": args.levels, "launches": launches}
+            have = {k: rec_t.get(k) for k in want}
+            if have == want:
+                traffic = int(rec_t["hbm_bytes_sweeps_per_step"] / max(launches, 1))
+                traffic_source = f"profiles/{PROFILE_ROUND}/traffic.json (rocprofv3 --pmc passes of this build and shape; not measured by this run)"
+            else:
+                traffic_source = f"profiles/{PROFILE_ROUND}/traffic.json does not describe this build/shape ({ {k: (have[k], want[k]) for k in want if have[k] != want[k]} }): null"
         roofline = {"bound": "hbm", "kernel": "k_blur_iter_fast (all sweep launches of a step)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                     "avg_launch_ms": round(ms / max(launches, 1), 4), "launches_per_step": launches,
                     "alg_bytes_per_launch_avg": int(bytes_step / max(launches, 1)),
                     "kernel_share_of_step": round(ms / (1e3 * elapsed / args.steps), 3),
                     "all_kernels_ms": {k: round(v[0], 3) for k, v in prof.items()}}
 
+    failed = False
     if rank == 0:
         pairs = world * B * args.steps
         value = pairs / elapsed
@@ -251,22 +349,33 @@ def main():
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"{W}x{H}, batch={B} frame pairs per GPU, Farneback(0.4,{ctx.fb.levels},12,10,8,1.2,0) "
                                       f"+ FoE(1000 pairs) + phi/threshold + box, {len(layers)} pyramid layers",
-                          "global_batch": world * B, "parallelism": f"frame-parallel x{world}" + (", RCCL all-gather of 32-B records" if world > 1 else "")},
+                          "global_batch": world * B, "parallelism": f"frame-parallel x{world}" + (", all-gather of 32-B records" if world > 1 else ""),
+                          "record_exchange": exchange},
                "hip_event_ms_per_step": round(ev_ms / args.steps, 3),
                "pipeline_alg_bytes_per_pair": balg,
-               "pipeline_frac_of_hbm_peak": round(value / world * balg / (HBM_PEAK_GBS * 1e9), 4)}
+               "pipeline_frac_of_hbm_peak": round(value / world * balg / (HBM_PEAK_GBS * 1e9), 4),
+               "source_hash": source_hash()}
+        if world > 1:
+            out["scaling_note"] = "per-GPU work fixed (weak); efficiency is the driver's to compute from the per-N values"
         if h2d_ms:
             out["value_incl_h2d"] = round(B / (h2d_ms * 1e-3), 2)
             out["value_incl_h2d_pipelined"] = round(B / (h2d_pipe_ms * 1e-3), 2)
         if roofline:
             out["roofline"] = roofline
+        if verification:
+            out.update({"verified_pairs": verification["verified_pairs"], "verification": {k: v for k, v in verification.items() if k != "verified_pairs"}})
+            failed = bool(verification["failed_pairs"])
         if world == 1 and args.cpu_pairs > 0:
-            out["cpu_baseline"] = cpu_baseline(prev, nxt, samples, min(args.cpu_pairs, B), gpu_flow_fn=ctx.farneback)
+            out["cpu_baseline"] = cpu_baseline(prev, nxt, samples, min(args.cpu_pairs, B), args.levels)
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        ctx.comm_destroy(comm)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+    if failed:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

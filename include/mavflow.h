@@ -97,6 +97,14 @@ int mav_bgr2gray(mav_ctx*, const uint8_t* bgr, int batch, uint8_t* gray);
  * sky: (batch,H,W) u8 or NULL; phi (degrees), mask_fixed, mask_dyn, max_phi (batch) are each optional (NULL). */
 int mav_phi_mask(mav_ctx*, const double* flow, const double* foe, const uint8_t* sky, int batch, const mav_thr_params*,
                  double* phi, uint8_t* mask_fixed, uint8_t* mask_dyn, double* max_phi);
+/* The same two calls handed a FLOAT32 flow array, which is what the reference does for frame index 0 (derotate returns its
+ * input, src/detector.py:80-81): numpy then evaluates the |flow2| gate (:78), get_phi (:163-177, zeros_like keeps float32) and
+ * the threshold block in float32.  Same arithmetic here, in numpy's operation order; the line intersections stay in double
+ * (float32 + uint32 promotes).  phi / max_phi are float32.  arccos: correctly rounded float32 (numpy's own float32 arccos is a
+ * SIMD routine up to 2 ulp away from that, host dependent -- see tests/test_gpu_frame0.py). */
+int mav_foe_dense_f32(mav_ctx*, const float* flow, const uint32_t* samples, int batch, const mav_foe_params*, double* foe);
+int mav_phi_mask_f32(mav_ctx*, const float* flow, const double* foe, const uint8_t* sky, int batch, const mav_thr_params*,
+                     float* phi, uint8_t* mask_fixed, uint8_t* mask_dyn, float* max_phi);
 /* im_helpers.get_simple_bounding_box [src/im_helpers.py:55-84] on u8 images: box (batch,4) = x0,y0,x1,y1, -1 if empty. */
 int mav_bbox(mav_ctx*, const uint8_t* img, int batch, int32_t* box);
 /* Level 0 of Detector.analyze_pyramid [src/detector.py:280-312] on the 3-channel replica of a u8 image:
@@ -117,22 +125,45 @@ int mav_pyramid_dims(const mav_ctx*, double scale, int level, int* w, int* h); /
  * windows that leave the image).  window_in / window_out (batch,4) = x, y, w, h; score (batch) = 3 * enclosed sum, 0 and the
  * unchanged window when no neighbour has a positive sum. */
 int mav_optimize_window(mav_ctx*, const uint8_t* img, int batch, const int32_t* window_in, int64_t* score, int32_t* window_out);
-/* im_helpers.calculate_tpr_fpr [src/im_helpers.py:244-252] for a 0/255 ground truth and a 0/1 mask:
+/* im_helpers.calculate_tpr_fpr [src/im_helpers.py:244-252]: positives = #(gt > 127), negatives = #(255 - gt > 127),
+ * tp = #(gt * img > 127), fp = #((255 - gt) * img > 127), where img = mask_value at the set pixels of `mask` (any nonzero byte)
+ * and 0 elsewhere, products in wide integers as numpy forms them for the reference's own argument 255 * mask (mask_value 255,
+ * src/processor.py:350-351) or for a bool mask (mask_value 1).  gt: any u8 image.
  * counts (batch,4) = positives, negatives, true positives, false positives. */
-int mav_tpr_fpr_counts(mav_ctx*, const uint8_t* gt, const uint8_t* mask, int batch, int64_t* counts);
+int mav_tpr_fpr_counts(mav_ctx*, const uint8_t* gt, const uint8_t* mask, int mask_value, int batch, int64_t* counts);
 
 /* The fused loop body of Processor.run_detection [src/processor.py:305-341] for `batch` pairs:
  * frames -> flow -> (derotate) -> FoE -> phi -> masks -> box. omega/dt NULL = no rotation (dt = 1);
- * sky NULL = no sky; flow / mask_fixed / mask_dyn / phi outputs are optional (NULL). results (batch). */
+ * sky NULL = no sky; flow / mask_fixed / mask_dyn / phi outputs are optional (NULL). results (batch).
+ * frame0 (batch) u8 flags or NULL: a nonzero flag marks a pair as the reference's frame index 0, for which
+ * Detector.derotate returns the float32 flow untouched [src/detector.py:80-81] and every numpy expression after it
+ * (|flow2| gate of get_FOE_dense :78, get_phi :163-177, the threshold block) therefore runs in FLOAT32: that pair is not
+ * derotated and is evaluated in float32 arithmetic in numpy's operation order (phi, if requested, is the float32 value
+ * widened).  Pairs without the flag follow the float64 path of every later frame. */
 int mav_process_batch(mav_ctx*, const uint8_t* prev, const uint8_t* next, const uint32_t* samples, const double* omega,
-                      const double* dt, const uint8_t* sky, int batch, const mav_foe_params*, const mav_thr_params*,
-                      float* flow, double* phi, uint8_t* mask_fixed, uint8_t* mask_dyn, mav_result* results);
+                      const double* dt, const uint8_t* frame0, const uint8_t* sky, int batch, const mav_foe_params*,
+                      const mav_thr_params*, float* flow, double* phi, uint8_t* mask_fixed, uint8_t* mask_dyn,
+                      mav_result* results);
+/* The same loop body from the reference's own flow seam [src/datasets/dataset.py:205-212 -> src/processor.py:305-341]:
+ * `flow` is the float32 (batch, H, W, 2) field Dataset.get_flow_uv returns (a .flo file, or mav_farneback's output);
+ * derotation, FoE, phi, masks and box as in mav_process_batch.  One upload of the flow, no other transfer of it. */
+int mav_detect(mav_ctx*, const float* flow, const uint32_t* samples, const double* omega, const double* dt,
+               const uint8_t* frame0, const uint8_t* sky, int batch, const mav_foe_params*, const mav_thr_params*, double* phi,
+               uint8_t* mask_fixed, uint8_t* mask_dyn, mav_result* results);
 
 /* ---- device-pointer entry points (asynchronous on the context's stream) -------------------------------- */
 int mav_farneback_dev(mav_ctx*, const uint8_t* prev, const uint8_t* next, int batch, float* flow);
 int mav_process_batch_dev(mav_ctx*, const uint8_t* prev, const uint8_t* next, const uint32_t* samples, const double* omega,
-                          const double* dt, const uint8_t* sky, int batch, const mav_foe_params*, const mav_thr_params*,
-                          float* flow, double* phi, uint8_t* mask_fixed, uint8_t* mask_dyn, mav_result* results);
+                          const double* dt, const uint8_t* frame0, const uint8_t* sky, int batch, const mav_foe_params*,
+                          const mav_thr_params*, float* flow, double* phi, uint8_t* mask_fixed, uint8_t* mask_dyn,
+                          mav_result* results);
+int mav_detect_dev(mav_ctx*, const float* flow, const uint32_t* samples, const double* omega, const double* dt,
+                   const uint8_t* frame0, const uint8_t* sky, int batch, const mav_foe_params*, const mav_thr_params*,
+                   double* phi, uint8_t* mask_fixed, uint8_t* mask_dyn, mav_result* results);
+/* Device pointer of the flow field the most recent mav_process_batch_dev / mav_farneback_dev call on this context wrote
+ * (the caller's buffer, or the context's own workspace when the caller passed flow == NULL); NULL before the first call.
+ * Lets a caller that keeps the flow in the workspace (bench.py) still inspect it. */
+const float* mav_last_flow_dev(const mav_ctx*);
 int mav_sync(mav_ctx*);
 void* mav_stream(mav_ctx*); /* the context's hipStream_t */
 
@@ -142,8 +173,11 @@ int mav_dev_free(mav_ctx*, void* p);
 int mav_memcpy_h2d(mav_ctx*, void* dst, const void* src, size_t bytes);
 int mav_memcpy_d2h(mav_ctx*, void* dst, const void* src, size_t bytes);
 
-/* Overlapped uploads: pinned host memory, copies on a second stream, and a fence that makes everything enqueued on the
- * context's stream AFTER the fence wait for the copies issued BEFORE it (double-buffered batches hide PCIe). */
+/* Overlapped uploads: pinned host memory and copies on a second stream, ordered against the compute stream in BOTH
+ * directions: mav_upload_async first makes the copy stream wait for everything enqueued on the context's stream so far
+ * (so a buffer set is never overwritten while an earlier batch still reads it), and mav_upload_fence makes everything
+ * enqueued on the context's stream AFTER the fence wait for the copies issued BEFORE it.  Double-buffered batches:
+ *   upload_async(set B) ; process_batch_dev(set A) ; upload_fence() ; upload_async(set A) ; process_batch_dev(set B) ; ... */
 int mav_host_alloc(mav_ctx*, size_t bytes, void** out);
 int mav_host_free(mav_ctx*, void* p);
 int mav_upload_async(mav_ctx*, void* dst_dev, const void* src_host, size_t bytes);
@@ -174,6 +208,18 @@ int mav_stage_update_matrices(mav_ctx*, const float* R0, const float* R1, const 
 /* one FarnebackUpdateFlow_Blur sweep at layer k: M (5,h,w) -> flow (h,w,2) and, if update != 0, M_out (5,h,w) */
 int mav_stage_blur_iter(mav_ctx*, const float* R0, const float* R1, const float* M, int k, int update, float* flow,
                         float* M_out);
+
+/* The phi / mask / box stage exactly as the fused path runs it (float32 flow from the flow stage, derotation on the fly,
+ * double arithmetic, single-precision screen when phi == NULL) but with a caller-supplied FoE (batch, 2) instead of the RANSAC
+ * fit: lets a test plant pixels around every threshold for a known FoE.  omega / dt / sky / phi / masks / box may be NULL;
+ * box (batch, 4) = x0, y0, x1, y1 of the fixed mask. */
+int mav_stage_phi_mask(mav_ctx*, const float* flow, const double* foe, const double* omega, const double* dt, const uint8_t* sky,
+                       int batch, const mav_thr_params*, double* phi, uint8_t* mask_fixed, uint8_t* mask_dyn, int32_t* box);
+
+/* The constants the flow kernels run on, as the library derived them (parity tests compare them with an independent
+ * derivation): FarnebackPrepareGaussian(poly_n, poly_sigma) -> g, xg, xxg (poly_n + 1 floats each, centre tap first) and
+ * ig = {ig11, ig03, ig33, ig55}; and, when k >= 0, layer k's GaussianBlur taps (its ksize floats).  Any pointer may be NULL. */
+int mav_stage_coefficients(mav_ctx*, int k, float* g, float* xg, float* xxg, float* ig, float* blur_taps);
 
 /* pyramid level `level` (>= 0) of one u8 image: (h_l, w_l) u8, sizes from mav_pyramid_dims */
 int mav_stage_pyramid_level(mav_ctx*, const uint8_t* img, double scale, int level, uint8_t* out);

@@ -14,12 +14,14 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 // Derotated flow vector at pixel (col, row) in double, reference operation order (detector.py:92-114).
 static __device__ __forceinline__ void derot_apply(float2 f, const DerotParams* __restrict__ dp, int W, int H, int row, int col,
                                                    double* fu, double* fv)
 {
     double u = (double)f.x, v = (double)f.y;
-    if (dp && dp->enabled) {
+    if (dp && dp->mode == MAV_PAIR_DEROTATE) {
         const double x = -((double)col / (double)W - 0.5) * 2.0;
         const double y = -((double)row / (double)H - 0.5) * 2.0;
         const double o0 = dp->o0, o1 = dp->o1, o2 = dp->o2;
@@ -77,7 +79,7 @@ void launch_derotate(hipStream_t st, const float* flow, const DerotParams* derot
 template <typename FlowT>
 __global__ __launch_bounds__(1024) void k_foe_candidates(const FlowT* __restrict__ flow, const DerotParams* __restrict__ derot,
                                                          const uint32_t* __restrict__ samples, int W, int H, int N,
-                                                         double mag2_thr, FoeScratch sc)
+                                                         double mag2_thr, float mag2_thr_f32, FoeScratch sc)
 {
     __shared__ int wave_tot[16];
     __shared__ int base_s;
@@ -85,6 +87,9 @@ __global__ __launch_bounds__(1024) void k_foe_candidates(const FlowT* __restrict
     const size_t img = (size_t)W * H * 2;
     const FlowT* fl = flow + b * img;
     const DerotParams* dp = derot ? derot + b : nullptr;
+    // frame-0 pair (float32 flow handed to numpy as is): only the |flow2| gate runs in float32 there -- `flow + coord` is
+    // float32 + uint32 = float64, so the intersections below are the same double arithmetic either way
+    const bool f32_gate = std::is_same<FlowT, float>::value && dp && dp->mode == MAV_PAIR_FRAME0;
     const uint32_t* smp = samples + (size_t)b * 4 * N;
     double* cand = sc.cand + (size_t)b * 2 * N;
     if (tid == 0) { base_s = 0; sc.best_key[b] = 0ull; }
@@ -101,7 +106,13 @@ __global__ __launch_bounds__(1024) void k_foe_candidates(const FlowT* __restrict
                 flow_at(fl, dp, W, H, (int)r1, (int)c1, &f1x, &f1y);
                 flow_at(fl, dp, W, H, (int)r2, (int)c2, &f2x, &f2y);
                 const double mag2 = f2x * f2x + f2y * f2y;
-                if (!(mag2 < mag2_thr)) {  // == !(sqrt(mag2) < mag_threshold), see sq_threshold() on the host
+                bool below = mag2 < mag2_thr;      // == sqrt(mag2) < mag_threshold, see sq_threshold() on the host
+                if (f32_gate) {                    // np.linalg.norm of a float32 pair: float32 products, sum and root
+                    const float gx = (float)f2x, gy = (float)f2y;
+                    const float m2 = gx * gx + gy * gy;
+                    below = m2 < mag2_thr_f32;
+                }
+                if (!below) {
                     const double p1x = (double)c1, p1y = (double)r1, p2x = (double)c2, p2y = (double)r2;
                     const double q1x = f1x + p1x, q1y = f1y + p1y, q2x = f2x + p2x, q2y = f2y + p2y;
                     const double xd0 = p1x - q1x, xd1 = p2x - q2x, yd0 = p1y - q1y, yd1 = p2y - q2y;
@@ -185,21 +196,21 @@ __global__ void k_foe_finalize(FoeScratch sc, int N, int B, double* __restrict__
 
 template <typename FlowT>
 static void launch_foe_t(hipStream_t st, const FlowT* flow, const DerotParams* derot, const uint32_t* samples, int B, int W,
-                         int H, int N, double mag2_thr, double dist2_thr, FoeScratch s, double* foe)
+                         int H, int N, double mag2_thr, float mag2_thr_f32, double dist2_thr, FoeScratch s, double* foe)
 {
-    hipLaunchKernelGGL(k_foe_candidates<FlowT>, dim3(B), dim3(1024), 0, st, flow, derot, samples, W, H, N, mag2_thr, s);
+    hipLaunchKernelGGL(k_foe_candidates<FlowT>, dim3(B), dim3(1024), 0, st, flow, derot, samples, W, H, N, mag2_thr, mag2_thr_f32, s);
     hipLaunchKernelGGL(k_ransac, dim3((N + 255) / 256, B), dim3(256), sizeof(double2) * (size_t)N, st, s, N, dist2_thr);
     hipLaunchKernelGGL(k_foe_finalize, dim3((B + 63) / 64), dim3(64), 0, st, s, N, B, foe);
 }
 void launch_foe_f32(hipStream_t st, const float* flow, const DerotParams* derot, const uint32_t* samples, int B, int W, int H,
-                    int N, double mag2_thr, double dist2_thr, FoeScratch s, double* foe)
+                    int N, double mag2_thr, float mag2_thr_f32, double dist2_thr, FoeScratch s, double* foe)
 {
-    launch_foe_t<float>(st, flow, derot, samples, B, W, H, N, mag2_thr, dist2_thr, s, foe);
+    launch_foe_t<float>(st, flow, derot, samples, B, W, H, N, mag2_thr, mag2_thr_f32, dist2_thr, s, foe);
 }
 void launch_foe_f64(hipStream_t st, const double* flow, const uint32_t* samples, int B, int W, int H, int N, double mag2_thr,
                     double dist2_thr, FoeScratch s, double* foe)
 {
-    launch_foe_t<double>(st, flow, nullptr, samples, B, W, H, N, mag2_thr, dist2_thr, s, foe);
+    launch_foe_t<double>(st, flow, nullptr, samples, B, W, H, N, mag2_thr, 0.f, dist2_thr, s, foe);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -307,6 +318,35 @@ static __device__ __forceinline__ void phi_pixel(double u, double v, int x, int 
     *have_ph = true;
 }
 
+// One pixel of a frame-0 pair: get_phi (focus_of_expansion.py:163-177) and the threshold block (processor.py:333-341) as numpy
+// evaluates them on a FLOAT32 flow array -- zeros_like keeps diff2 in float32 (the int64 - float64 coordinate difference is
+// rounded into it), np.linalg.norm, the products, the quotient and the thresholds (8 / mag, 0.5 + ..., 0.25 + ...) are all
+// float32 operations, rad2deg multiplies by 180f / pif.  No contraction (this file is built with -ffp-contract=off).
+// arccos: the correctly rounded float32 value (double acos, rounded once).
+struct ThrF32 { float fixed_deg, fixed_min_mag, dyn_min_mag, dyn_a, dyn_b, dyn_c; };
+static __device__ __forceinline__ void phi_pixel_f32(float u, float v, int x, int y, double foex, double foey, bool notsky,
+                                                     const ThrF32& t, bool* fix_out, bool* dyn_out, float* ph_out)
+{
+    const float d2x = (float)((double)x - foex), d2y = (float)((double)y - foey);
+    const float fm = sqrtf(u * u + v * v);
+    const float dist = sqrtf(d2x * d2x + d2y * d2y);
+    const float prod = fm * dist;
+    const float norm = (prod > 1e-6f || prod != prod) ? prod : 1e-6f;      // np.maximum propagates NaN
+    float arg = (u * d2x + v * d2y) / norm;
+    float ph = 0.f;                                                         // angle_diff[isnan] = 0
+    if (arg == arg) {
+        arg = arg < -1.f ? -1.f : (arg > 1.f ? 1.f : arg);
+        ph = (float)acos((double)arg) * __int_as_float(0x42652EE0);         // 180.0f / 3.14159274f
+    }
+    const float tt = t.dyn_b + t.dyn_c / fm;
+    const bool hi = ph > (t.dyn_a + tt);
+    const bool lo = ph < (t.dyn_a - tt);
+    *dyn_out = (fm > t.dyn_min_mag) && notsky && (lo || hi);
+    const float gated = ((fm > t.fixed_min_mag) && notsky) ? ph : 0.f;
+    *fix_out = gated > t.fixed_deg;
+    *ph_out = ph;
+}
+
 // VEC = 4: one thread = 4 consecutive pixels x 4 rows (W % 4 == 0): float4 / double2 row loads, uchar4 mask stores;
 // workgroup = 256 columns x 16 rows.  VEC = 1: any width, one pixel per lane and row, 4 rows per thread.
 template <typename FlowT, int VEC>
@@ -321,6 +361,9 @@ __global__ __launch_bounds__(256) void k_phi_mask(const FlowT* __restrict__ flow
     const size_t npx = (size_t)W * H;
     const FlowT* fl = flow + b * npx * 2;
     const DerotParams* dp = derot ? derot + b : nullptr;
+    const bool f32_pair = std::is_same<FlowT, float>::value && dp && dp->mode == MAV_PAIR_FRAME0;
+    const ThrF32 thr32{(float)thr.fixed_deg, (float)thr.fixed_min_mag, (float)thr.dyn_min_mag, (float)thr.dyn_a, (float)thr.dyn_b,
+                       (float)thr.dyn_c};
     const double foex = foe[2 * b], foey = foe[2 * b + 1];
     int bx0 = INT_MAX, by0 = INT_MAX, bx1 = -1, by1 = -1;
     double pmax = 0.0;
@@ -353,11 +396,18 @@ __global__ __launch_bounds__(256) void k_phi_mask(const FlowT* __restrict__ flow
 #pragma unroll
         for (int j = 0; j < VEC; j++) {
             const int x = xb + j;
-            double u, v;
-            derot_apply(raw[r][j], dp, W, H, y, x, &u, &v);
             bool fix, dyn, have;
             double ph = 0.0;
-            phi_pixel(u, v, x, y, foex, foey, sk[j] == 0, thr, scr, &fix, &dyn, &ph, &have);
+            if (f32_pair) {
+                float ph32;
+                phi_pixel_f32((float)raw[r][j].x, (float)raw[r][j].y, x, y, foex, foey, sk[j] == 0, thr32, &fix, &dyn, &ph32);
+                ph = (double)ph32;
+                have = true;
+            } else {
+                double u, v;
+                derot_apply(raw[r][j], dp, W, H, y, x, &u, &v);
+                phi_pixel(u, v, x, y, foex, foey, sk[j] == 0, thr, scr, &fix, &dyn, &ph, &have);
+            }
             if (have) {
                 if (phi_out) phi_out[o + j] = ph;
                 pmax = ph > pmax ? ph : pmax;
@@ -545,8 +595,8 @@ void launch_window_max(hipStream_t st, const uint8_t* img, int B, int W, int H, 
     hipLaunchKernelGGL(k_window_finalize, dim3((B + 63) / 64), dim3(64), 0, st, key, nwx > 0 ? nwx : 1, B, out);
 }
 
-// calculate_tpr_fpr counts for gt (u8) against 255*mask (mask 0/1): see the header for the integer identities.
-__global__ __launch_bounds__(256) void k_tpr_fpr(const uint8_t* __restrict__ gt, const uint8_t* __restrict__ mask, size_t npx,
+// calculate_tpr_fpr counts for gt (u8) against mask_value * mask: the reference's products in wide integers (no u8 wrap).
+__global__ __launch_bounds__(256) void k_tpr_fpr(const uint8_t* __restrict__ gt, const uint8_t* __restrict__ mask, unsigned mask_value, size_t npx,
                                                  unsigned long long* __restrict__ counts)
 {
     const int b = blockIdx.y;
@@ -554,7 +604,7 @@ __global__ __launch_bounds__(256) void k_tpr_fpr(const uint8_t* __restrict__ gt,
     const uint8_t* m = mask + b * npx;
     unsigned pos = 0, neg = 0, tp = 0, fp = 0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npx; i += (size_t)gridDim.x * 256) {
-        const unsigned gv = g[i], mv = m[i] ? 255u : 0u;
+        const unsigned gv = g[i], mv = m[i] ? mask_value : 0u;
         pos += gv > 127u;
         neg += (255u - gv) > 127u;
         tp += (gv * mv) > 127u;
@@ -568,10 +618,11 @@ __global__ __launch_bounds__(256) void k_tpr_fpr(const uint8_t* __restrict__ gt,
         atomicAdd(&counts[4 * b + 2], (unsigned long long)tp); atomicAdd(&counts[4 * b + 3], (unsigned long long)fp);
     }
 }
-void launch_tpr_fpr(hipStream_t st, const uint8_t* gt, const uint8_t* mask, int B, int W, int H, unsigned long long* counts)
+void launch_tpr_fpr(hipStream_t st, const uint8_t* gt, const uint8_t* mask, unsigned mask_value, int B, int W, int H,
+                    unsigned long long* counts)
 {
     hipMemsetAsync(counts, 0, sizeof(unsigned long long) * 4 * B, st);
-    hipLaunchKernelGGL(k_tpr_fpr, dim3(128, B), dim3(256), 0, st, gt, mask, (size_t)W * H, counts);
+    hipLaunchKernelGGL(k_tpr_fpr, dim3(128, B), dim3(256), 0, st, gt, mask, mask_value, (size_t)W * H, counts);
 }
 
 // cv2.cvtColor(COLOR_BGR2GRAY) on u8 (farneback.py:21,74): fixed point, (B*1868 + G*9617 + R*4899 + 8192) >> 14  (SURVEY A.7).
@@ -602,20 +653,21 @@ void launch_ransac_only(hipStream_t st, FoeScratch s, int M, int N, double dist2
 }
 
 // DerotParams from device-resident omega (B,3) and dt (B, nullable = 1): sx = w*dt/2, sy = h*dt/2 (detector.py:101-102).
-__global__ void k_make_derot(const double* __restrict__ omega, const double* __restrict__ dt, int B, int W, int H,
-                             DerotParams* __restrict__ out)
+__global__ void k_make_derot(const double* __restrict__ omega, const double* __restrict__ dt, const uint8_t* __restrict__ frame0,
+                             int B, int W, int H, DerotParams* __restrict__ out)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const double d = dt ? dt[b] : 1.0;
     DerotParams p;
-    p.o0 = omega[3 * b]; p.o1 = omega[3 * b + 1]; p.o2 = omega[3 * b + 2];
+    p.o0 = omega ? omega[3 * b] : 0.0; p.o1 = omega ? omega[3 * b + 1] : 0.0; p.o2 = omega ? omega[3 * b + 2] : 0.0;
     p.sx = (double)W * d / 2;
     p.sy = (double)H * d / 2;
-    p.enabled = 1;
+    p.mode = (frame0 && frame0[b]) ? MAV_PAIR_FRAME0 : (omega ? MAV_PAIR_DEROTATE : MAV_PAIR_PROMOTE);
     out[b] = p;
 }
-void launch_make_derot(hipStream_t st, const double* omega, const double* dt, int B, int W, int H, DerotParams* out)
+void launch_make_derot(hipStream_t st, const double* omega, const double* dt, const uint8_t* frame0, int B, int W, int H,
+                       DerotParams* out)
 {
-    hipLaunchKernelGGL(k_make_derot, dim3((B + 63) / 64), dim3(64), 0, st, omega, dt, B, W, H, out);
+    hipLaunchKernelGGL(k_make_derot, dim3((B + 63) / 64), dim3(64), 0, st, omega, dt, frame0, B, W, H, out);
 }

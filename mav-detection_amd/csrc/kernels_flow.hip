@@ -1045,15 +1045,19 @@ void launch_blur_iter(hipStream_t st, const float* M_in, float* M_out, size_t M_
     if (m == 6)
         hipLaunchKernelGGL(k_blur_iter_generic<6>, grid, dim3(256), lds, st, M_in, M_out, M_stride, R0, R1, R_stride, w, h, m,
                            pitch, plane, scale, do_update, flow, f_stride);
-    else {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)k_blur_iter_generic<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
-        }
+    else       // dynamic LDS above the default limit was granted by blur_iter_prepare() when the context was created
         hipLaunchKernelGGL(k_blur_iter_generic<0>, grid, dim3(256), lds, st, M_in, M_out, M_stride, R0, R1, R_stride, w, h, m,
                            pitch, plane, scale, do_update, flow, f_stride);
-    }
+}
+
+// The general-winsize sweep needs 5 x (32 + 2m)^2 floats of dynamic LDS; above the 64 KB default a kernel must be granted
+// the size on every device it runs on.  Called by mav_create on the context's device; returns an error text or nullptr.
+const char* blur_iter_prepare(int winsize)
+{
+    const size_t lds = blur_iter_lds_bytes(winsize);
+    if (lds <= (size_t)64 * 1024) return nullptr;
+    const hipError_t e = hipFuncSetAttribute((const void*)k_blur_iter_generic<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }
 
 // One recompute sweep.  mode 0: zero flow in; 1: fin = coarser layer's flow (ph x pw x 2), upsampled * mul; 2: fin = this

@@ -69,6 +69,18 @@ static double sq_threshold(double t)
     return T;
 }
 
+// float32 twin for frame-0 pairs: numpy compares sqrt_f32(m2) with the threshold rounded to float32 (a Python float next to a
+// float32 scalar is "weak"), so  sqrtf(v) < (float)t  <=>  v < T32  with T32 the smallest float whose rounded root is >= (float)t.
+static float sq_threshold_f32(double t)
+{
+    const float tf = (float)t;
+    if (!(tf > 0)) return 0.f;
+    float T = tf * tf;
+    while (sqrtf(nextafterf(T, -INFINITY)) >= tf) T = nextafterf(T, -INFINITY);
+    while (sqrtf(T) < tf) T = nextafterf(T, INFINITY);
+    return T;
+}
+
 static void gaussian_kernel(int n, double sigma, std::vector<float>& k)  // getGaussianKernel(n, sigma, CV_32F)
 {
     static const float small_tab[4][7] = {{1.f},
@@ -175,7 +187,8 @@ struct mav_ctx {
     mav_fb_params fb;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;   // uploads that overlap the compute stream (mav_upload_async / mav_upload_fence)
-    hipEvent_t copy_done = nullptr;
+    hipEvent_t copy_done = nullptr, compute_mark = nullptr;
+    const float* last_flow = nullptr;    // where the latest farneback / process_batch call wrote its flow (mav_last_flow_dev)
     std::vector<Layer> layers;
     PolyCoef pc;
     // workspace (group slots)
@@ -192,6 +205,11 @@ struct mav_ctx {
     unsigned long long* u64_scratch = nullptr;  // [max_batch*4]
     int* i32_scratch = nullptr;                 // [max_batch]
     DerotParams* derot_dev = nullptr;
+    // staging buffers of the host-pointer entry points: slot i of a call re-uses the block slot i of the previous call
+    // left behind (grow-only), so the staged path performs no hipMalloc / hipFree once warm
+    struct Block { void* p = nullptr; size_t cap = 0; };
+    std::vector<Block> scratch;
+    size_t scratch_next = 0;
     uint8_t* pyr_ws = nullptr;                  // analyze_pyramid level images (lazily, max_batch)
     size_t pyr_ws_bytes = 0;
     unsigned long long* sat = nullptr;          // optimize_window summed-area tables (lazily, max_batch)
@@ -220,20 +238,25 @@ static void free_layer(Layer& l)
     l.g = nullptr;
 }
 
+// Workspace for `group` slots.  The new set is allocated in full before the old one is released: when an allocation fails the
+// context keeps its previous group and stays usable (the caller sees MAV_ERR_OOM).
 static int alloc_group(mav_ctx* c, int group)
 {
-    float** bufs[] = {&c->I, &c->R0, &c->R1, &c->Ma, &c->Mb, &c->fc[0], &c->fc[1], &c->Htmp};
-    for (auto b : bufs) { if (*b) hipFree(*b); *b = nullptr; }
+    float** bufs[8] = {&c->I, &c->R0, &c->R1, &c->Ma, &c->Mb, &c->fc[0], &c->fc[1], &c->Htmp};
+    const size_t g = (size_t)group, nc = 2 * (c->n1 ? c->n1 : 1);
+    const size_t elems[8] = {c->n0 * g, 5 * c->n0 * g, 5 * c->n0 * g, 5 * c->n0 * g, 5 * c->n0 * g, nc * g, nc * g, c->htmp_stride * g};
+    float* fresh[8] = {nullptr};
+    for (int i = 0; i < 8; i++) {
+        const hipError_t e = hipMalloc(&fresh[i], sizeof(float) * elems[i]);
+        if (e != hipSuccess) {
+            for (int j = 0; j < i; j++) hipFree(fresh[j]);
+            (void)hipGetLastError();
+            return fail(e == hipErrorOutOfMemory ? MAV_ERR_OOM : MAV_ERR_HIP, "workspace for group %d (%zu bytes for buffer %d): %s", group,
+                        sizeof(float) * elems[i], i, hipGetErrorString(e));
+        }
+    }
+    for (int i = 0; i < 8; i++) { if (*bufs[i]) hipFree(*bufs[i]); *bufs[i] = fresh[i]; }
     c->group = group;
-    const size_t g = (size_t)group;
-    HIPCHK(hipMalloc(&c->I, sizeof(float) * c->n0 * g));
-    HIPCHK(hipMalloc(&c->R0, sizeof(float) * 5 * c->n0 * g));
-    HIPCHK(hipMalloc(&c->R1, sizeof(float) * 5 * c->n0 * g));
-    HIPCHK(hipMalloc(&c->Ma, sizeof(float) * 5 * c->n0 * g));
-    HIPCHK(hipMalloc(&c->Mb, sizeof(float) * 5 * c->n0 * g));
-    HIPCHK(hipMalloc(&c->fc[0], sizeof(float) * 2 * (c->n1 ? c->n1 : 1) * g));
-    HIPCHK(hipMalloc(&c->fc[1], sizeof(float) * 2 * (c->n1 ? c->n1 : 1) * g));
-    HIPCHK(hipMalloc(&c->Htmp, sizeof(float) * c->htmp_stride * g));
     return MAV_OK;
 }
 
@@ -246,10 +269,12 @@ extern "C" int mav_destroy(mav_ctx* c)
     void* bufs[] = {c->I, c->R0, c->R1, c->Ma, c->Mb, c->fc[0], c->fc[1], c->Htmp, c->flow_ws, c->foe_sc.cand, c->foe_sc.count,
                     c->foe_sc.best_key, c->foe_dev, c->box_acc, c->u64_scratch, c->i32_scratch, c->derot_dev, c->pyr_ws, c->sat};
     for (void* b : bufs) if (b) hipFree(b);
+    for (auto& blk : c->scratch) if (blk.p) hipFree(blk.p);
     for (auto& r : c->prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     if (c->t0) hipEventDestroy(c->t0);
     if (c->t1) hipEventDestroy(c->t1);
     if (c->copy_done) hipEventDestroy(c->copy_done);
+    if (c->compute_mark) hipEventDestroy(c->compute_mark);
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -268,11 +293,18 @@ extern "C" int mav_create(mav_ctx** out, int device, int W, int H, int max_batch
         return fail(MAV_ERR_ARG, "unsupported Farneback parameters (levels=%d winsize=%d iterations=%d poly_n=%d)", fb.levels,
                     fb.winsize, fb.iterations, fb.poly_n);
     if (fb.flags != 0) return fail(MAV_ERR_ARG, "only flags == 0 (box window, no initial flow) is implemented, got %d", fb.flags);
+    if (fb.winsize / 2 != 6 && blur_iter_lds_bytes(fb.winsize) > (size_t)160 * 1024)
+        return fail(MAV_ERR_ARG, "winsize %d needs %zu bytes of LDS per workgroup in the general sweep kernel, the CU has 163840", fb.winsize,
+                    blur_iter_lds_bytes(fb.winsize));
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(MAV_ERR_STATE, "no HIP device visible: libmavflow has no CPU fallback");
     if (device < 0 || device >= ndev) return fail(MAV_ERR_ARG, "device %d out of range (%d visible)", device, ndev);
     HIPCHK(hipSetDevice(device));
+    if (fb.winsize / 2 != 6) {      // the general sweep kernel asks for more dynamic LDS than the default limit: per device, checked
+        const char* err = blur_iter_prepare(fb.winsize);
+        if (err) return fail(MAV_ERR_HIP, "winsize %d: %s", fb.winsize, err);
+    }
 
     mav_ctx* c = new mav_ctx();
     c->device = device; c->W = W; c->H = H; c->max_batch = max_batch; c->fb = fb;
@@ -282,6 +314,7 @@ extern "C" int mav_create(mav_ctx** out, int device, int W, int H, int max_batch
     HIPB(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPB(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     HIPB(hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming));
+    HIPB(hipEventCreateWithFlags(&c->compute_mark, hipEventDisableTiming));
     HIPB(hipEventCreate(&c->t0));
     HIPB(hipEventCreate(&c->t1));
     if (!prepare_poly(fb.poly_n, fb.poly_sigma, &c->pc)) { fail(MAV_ERR_ARG, "poly_sigma %g gives a singular moment matrix", fb.poly_sigma); return bail(MAV_ERR_ARG); }
@@ -416,6 +449,10 @@ extern "C" int mav_host_free(mav_ctx* c, void* p)
 extern "C" int mav_upload_async(mav_ctx* c, void* dst_dev, const void* src_host, size_t bytes)
 {
     if (!c || !dst_dev || !src_host) return fail(MAV_ERR_ARG, "mav_upload_async: NULL argument");
+    // the copy may overwrite a buffer that work already enqueued on the compute stream still reads (the previous user of a
+    // double-buffered set): order the copy stream behind everything enqueued there so far
+    HIPCHK(hipEventRecord(c->compute_mark, c->stream));
+    HIPCHK(hipStreamWaitEvent(c->copy_stream, c->compute_mark, 0));
     HIPCHK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->copy_stream));
     return MAV_OK;
 }
@@ -578,8 +615,10 @@ extern "C" int mav_farneback_dev(mav_ctx* c, const uint8_t* prev, const uint8_t*
         const int g = batch - g0 < c->group ? batch - g0 : c->group;
         CHK(farneback_group(c, prev + (size_t)g0 * c->n0, next + (size_t)g0 * c->n0, g, flow + (size_t)g0 * 2 * c->n0));
     }
+    c->last_flow = flow;
     return MAV_OK;
 }
+extern "C" const float* mav_last_flow_dev(const mav_ctx* c) { return c ? c->last_flow : nullptr; }
 
 // ---- detection ---------------------------------------------------------------------------------------------
 static int ensure_foe_scratch(mav_ctx* c, int N)
@@ -594,22 +633,23 @@ static int ensure_foe_scratch(mav_ctx* c, int N)
 
 // Per-pair derotation constants.  Device pointers stay on the device (a tiny kernel packs them: no host round trip, the
 // stream never drains); host pointers are packed here and copied.
-static int upload_derot(mav_ctx* c, const double* omega, const double* dt, int batch, bool host_ptrs, const DerotParams** out)
+static int upload_derot(mav_ctx* c, const double* omega, const double* dt, const uint8_t* frame0, int batch, bool host_ptrs,
+                        const DerotParams** out)
 {
     *out = nullptr;
-    if (!omega) return MAV_OK;
+    if (!omega && !frame0) return MAV_OK;
     if (!host_ptrs) {
-        launch_make_derot(c->stream, omega, dt, batch, c->W, c->H, c->derot_dev);
+        launch_make_derot(c->stream, omega, dt, frame0, batch, c->W, c->H, c->derot_dev);
         *out = c->derot_dev;
         return MAV_OK;
     }
     std::vector<DerotParams> dp(batch);
     for (int b = 0; b < batch; b++) {
         const double d = dt ? dt[b] : 1.0;
-        dp[b].o0 = omega[3 * b]; dp[b].o1 = omega[3 * b + 1]; dp[b].o2 = omega[3 * b + 2];
+        dp[b].o0 = omega ? omega[3 * b] : 0.0; dp[b].o1 = omega ? omega[3 * b + 1] : 0.0; dp[b].o2 = omega ? omega[3 * b + 2] : 0.0;
         dp[b].sx = c->W * d / 2;   // w * dt / 2   (detector.py:101)
         dp[b].sy = c->H * d / 2;
-        dp[b].enabled = 1;
+        dp[b].mode = (frame0 && frame0[b]) ? MAV_PAIR_FRAME0 : (omega ? MAV_PAIR_DEROTATE : MAV_PAIR_PROMOTE);
     }
     HIPCHK(hipMemcpyAsync(c->derot_dev, dp.data(), sizeof(DerotParams) * batch, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));  // dp is a local vector
@@ -633,7 +673,7 @@ static int detect_dev(mav_ctx* c, const float* flow32, const double* flow64, con
         ProfScope ps(c, K_FOE);
         if (flow32)
             launch_foe_f32(c->stream, flow32, derot, samples, batch, W, H, f.n_pairs, sq_threshold(f.mag_threshold),
-                           sq_threshold(f.ransac_threshold), c->foe_sc, fo);
+                           sq_threshold_f32(f.mag_threshold), sq_threshold(f.ransac_threshold), c->foe_sc, fo);
         else
             launch_foe_f64(c->stream, flow64, samples, batch, W, H, f.n_pairs, sq_threshold(f.mag_threshold),
                            sq_threshold(f.ransac_threshold), c->foe_sc, fo);
@@ -656,8 +696,23 @@ static int detect_dev(mav_ctx* c, const float* flow32, const double* flow64, con
     return check_launch("detection kernels");
 }
 
+extern "C" int mav_detect_dev(mav_ctx* c, const float* flow, const uint32_t* samples, const double* omega, const double* dt,
+                              const uint8_t* frame0, const uint8_t* sky, int batch, const mav_foe_params* fp,
+                              const mav_thr_params* tp, double* phi, uint8_t* mask_fixed, uint8_t* mask_dyn, mav_result* results)
+{
+    if (!c || !flow || !samples || !results) return fail(MAV_ERR_ARG, "mav_detect: NULL argument");
+    if (batch < 1 || batch > c->max_batch) return fail(MAV_ERR_ARG, "batch %d outside [1, %d]", batch, c->max_batch);
+    HIPCHK(hipSetDevice(c->device));
+    const DerotParams* derot = nullptr;
+    CHK(upload_derot(c, omega, dt, frame0, batch, false, &derot));
+    mav_thr_params t;
+    if (tp) t = *tp; else mav_thr_defaults(&t);
+    return detect_dev(c, flow, nullptr, derot, samples, sky, batch, fp, &t, nullptr, phi, mask_fixed, mask_dyn, nullptr, nullptr,
+                      results, nullptr);
+}
+
 extern "C" int mav_process_batch_dev(mav_ctx* c, const uint8_t* prev, const uint8_t* next, const uint32_t* samples,
-                                     const double* omega, const double* dt, const uint8_t* sky, int batch,
+                                     const double* omega, const double* dt, const uint8_t* frame0, const uint8_t* sky, int batch,
                                      const mav_foe_params* fp, const mav_thr_params* tp, float* flow, double* phi,
                                      uint8_t* mask_fixed, uint8_t* mask_dyn, mav_result* results)
 {
@@ -668,23 +723,32 @@ extern "C" int mav_process_batch_dev(mav_ctx* c, const uint8_t* prev, const uint
         if (!c->flow_ws) HIPCHK(hipMalloc(&c->flow_ws, sizeof(float) * 2 * c->n0 * c->max_batch));
         flow = c->flow_ws;
     }
-    const DerotParams* derot = nullptr;
-    CHK(upload_derot(c, omega, dt, batch, false, &derot));
     CHK(mav_farneback_dev(c, prev, next, batch, flow));
-    mav_thr_params t;
-    if (tp) t = *tp; else mav_thr_defaults(&t);
-    return detect_dev(c, flow, nullptr, derot, samples, sky, batch, fp, &t, nullptr, phi, mask_fixed, mask_dyn, nullptr, nullptr,
-                      results, nullptr);
+    return mav_detect_dev(c, flow, samples, omega, dt, frame0, sky, batch, fp, tp, phi, mask_fixed, mask_dyn, results);
 }
 
 // ---- host-pointer wrappers -----------------------------------------------------------------------------------
+// A staging buffer of one host-pointer call.  It borrows the context's next scratch block (grown when too small, never
+// shrunk or freed before mav_destroy): once a call shape has been seen the staged path allocates nothing.  The host entry
+// points are synchronous (they end in mav_sync), so a block is idle again when the next call takes it.
 struct DevBuf {
     void* p = nullptr;
-    ~DevBuf() { if (p) hipFree(p); }
-    int alloc(size_t bytes) { HIPCHK(hipMalloc(&p, bytes ? bytes : 1)); return MAV_OK; }
+    int alloc(mav_ctx* c, size_t bytes)
+    {
+        if (c->scratch_next == c->scratch.size()) c->scratch.emplace_back();
+        mav_ctx::Block& b = c->scratch[c->scratch_next++];
+        if (b.cap < bytes || !b.p) {
+            if (b.p) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(b.p); b.p = nullptr; b.cap = 0; }
+            const size_t want = bytes ? bytes : 1;
+            HIPCHK(hipMalloc(&b.p, want));
+            b.cap = want;
+        }
+        p = b.p;
+        return MAV_OK;
+    }
     int upload(mav_ctx* c, const void* src, size_t bytes)
     {
-        CHK(alloc(bytes));
+        CHK(alloc(c, bytes));
         HIPCHK(hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, c->stream));
         return MAV_OK;
     }
@@ -700,6 +764,7 @@ static int check_batch(mav_ctx* c, int batch, const char* fn)
     if (!c) return fail(MAV_ERR_ARG, "%s: NULL context", fn);
     if (batch < 1 || batch > c->max_batch) return fail(MAV_ERR_ARG, "%s: batch %d outside [1, %d]", fn, batch, c->max_batch);
     HIPCHK(hipSetDevice(c->device));
+    c->scratch_next = 0;              // a new host-pointer call: its staging buffers start again at block 0
     return MAV_OK;
 }
 
@@ -709,7 +774,7 @@ extern "C" int mav_farneback(mav_ctx* c, const uint8_t* prev, const uint8_t* nex
     if (!prev || !next || !flow) return fail(MAV_ERR_ARG, "mav_farneback: NULL argument");
     const size_t n = c->n0 * batch;
     DevBuf dp, dn, df;
-    CHK(dp.upload(c, prev, n)); CHK(dn.upload(c, next, n)); CHK(df.alloc(n * 2 * sizeof(float)));
+    CHK(dp.upload(c, prev, n)); CHK(dn.upload(c, next, n)); CHK(df.alloc(c, n * 2 * sizeof(float)));
     CHK(mav_farneback_dev(c, dp.as<uint8_t>(), dn.as<uint8_t>(), batch, df.as<float>()));
     CHK(download(c, flow, df.p, n * 2 * sizeof(float)));
     return mav_sync(c);
@@ -721,9 +786,9 @@ extern "C" int mav_derotate(mav_ctx* c, const float* flow, const double* omega, 
     if (!flow || !omega || !flow_out) return fail(MAV_ERR_ARG, "mav_derotate: NULL argument");
     const size_t n = c->n0 * batch * 2;
     DevBuf df, dout;
-    CHK(df.upload(c, flow, n * sizeof(float))); CHK(dout.alloc(n * sizeof(double)));
+    CHK(df.upload(c, flow, n * sizeof(float))); CHK(dout.alloc(c, n * sizeof(double)));
     const DerotParams* derot = nullptr;
-    CHK(upload_derot(c, omega, dt, batch, true, &derot));
+    CHK(upload_derot(c, omega, dt, nullptr, batch, true, &derot));
     launch_derotate(c->stream, df.as<float>(), derot, batch, c->W, c->H, dout.as<double>());
     CHK(check_launch("derotate"));
     CHK(download(c, flow_out, dout.p, n * sizeof(double)));
@@ -740,7 +805,7 @@ extern "C" int mav_foe_dense(mav_ctx* c, const double* flow, const uint32_t* sam
     DevBuf df, ds, dfoe;
     CHK(df.upload(c, flow, c->n0 * batch * 2 * sizeof(double)));
     CHK(ds.upload(c, samples, sizeof(uint32_t) * 4 * (size_t)f.n_pairs * batch));
-    CHK(dfoe.alloc(sizeof(double) * 2 * batch));
+    CHK(dfoe.alloc(c, sizeof(double) * 2 * batch));
     CHK(detect_dev(c, nullptr, df.as<double>(), nullptr, ds.as<uint32_t>(), nullptr, batch, &f, nullptr, nullptr, nullptr, nullptr,
                    nullptr, nullptr, dfoe.as<double>(), nullptr, nullptr));
     CHK(download(c, foe, dfoe.p, sizeof(double) * 2 * batch));
@@ -759,9 +824,9 @@ extern "C" int mav_phi_mask(mav_ctx* c, const double* flow, const double* foe, c
     CHK(df.upload(c, flow, n * 2 * sizeof(double)));
     CHK(dfoe.upload(c, foe, sizeof(double) * 2 * batch));
     if (sky) CHK(dsky.upload(c, sky, n));
-    if (phi) CHK(dphi.alloc(n * sizeof(double)));
-    if (mask_fixed) CHK(dmf.alloc(n));
-    if (mask_dyn) CHK(dmd.alloc(n));
+    if (phi) CHK(dphi.alloc(c, n * sizeof(double)));
+    if (mask_fixed) CHK(dmf.alloc(c, n));
+    if (mask_dyn) CHK(dmd.alloc(c, n));
     CHK(detect_dev(c, nullptr, df.as<double>(), nullptr, nullptr, dsky.as<uint8_t>(), batch, nullptr, &t, dfoe.as<double>(),
                    dphi.as<double>(), dmf.as<uint8_t>(), dmd.as<uint8_t>(), max_phi ? c->u64_scratch : nullptr, nullptr, nullptr,
                    nullptr));
@@ -772,12 +837,71 @@ extern "C" int mav_phi_mask(mav_ctx* c, const double* flow, const double* foe, c
     return mav_sync(c);
 }
 
+// ---- the same two calls on a float32 flow array (the reference's frame index 0): float32 arithmetic ----------------
+static int frame0_params(mav_ctx* c, int batch, const DerotParams** out)
+{
+    std::vector<uint8_t> all(batch, 1);
+    return upload_derot(c, nullptr, nullptr, all.data(), batch, true, out);
+}
+
+extern "C" int mav_foe_dense_f32(mav_ctx* c, const float* flow, const uint32_t* samples, int batch, const mav_foe_params* fp, double* foe)
+{
+    CHK(check_batch(c, batch, "mav_foe_dense_f32"));
+    if (!flow || !samples || !foe) return fail(MAV_ERR_ARG, "mav_foe_dense_f32: NULL argument");
+    mav_foe_params f;
+    if (fp) f = *fp; else mav_foe_defaults(&f);
+    if (f.n_pairs < 1 || f.n_pairs > 4096) return fail(MAV_ERR_ARG, "n_pairs %d outside [1, 4096]", f.n_pairs);
+    DevBuf df, ds, dfoe;
+    CHK(df.upload(c, flow, c->n0 * batch * 2 * sizeof(float)));
+    CHK(ds.upload(c, samples, sizeof(uint32_t) * 4 * (size_t)f.n_pairs * batch));
+    CHK(dfoe.alloc(c, sizeof(double) * 2 * batch));
+    const DerotParams* mode = nullptr;
+    CHK(frame0_params(c, batch, &mode));
+    CHK(detect_dev(c, df.as<float>(), nullptr, mode, ds.as<uint32_t>(), nullptr, batch, &f, nullptr, nullptr, nullptr, nullptr,
+                   nullptr, nullptr, dfoe.as<double>(), nullptr, nullptr));
+    CHK(download(c, foe, dfoe.p, sizeof(double) * 2 * batch));
+    return mav_sync(c);
+}
+
+extern "C" int mav_phi_mask_f32(mav_ctx* c, const float* flow, const double* foe, const uint8_t* sky, int batch,
+                                const mav_thr_params* tp, float* phi, uint8_t* mask_fixed, uint8_t* mask_dyn, float* max_phi)
+{
+    CHK(check_batch(c, batch, "mav_phi_mask_f32"));
+    if (!flow || !foe) return fail(MAV_ERR_ARG, "mav_phi_mask_f32: NULL argument");
+    const size_t n = c->n0 * batch;
+    mav_thr_params t;
+    if (tp) t = *tp; else mav_thr_defaults(&t);
+    DevBuf df, dfoe, dsky, dphi, dmf, dmd;
+    CHK(df.upload(c, flow, n * 2 * sizeof(float)));
+    CHK(dfoe.upload(c, foe, sizeof(double) * 2 * batch));
+    if (sky) CHK(dsky.upload(c, sky, n));
+    if (phi) CHK(dphi.alloc(c, n * sizeof(double)));
+    if (mask_fixed) CHK(dmf.alloc(c, n));
+    if (mask_dyn) CHK(dmd.alloc(c, n));
+    const DerotParams* mode = nullptr;
+    CHK(frame0_params(c, batch, &mode));
+    CHK(detect_dev(c, df.as<float>(), nullptr, mode, nullptr, dsky.as<uint8_t>(), batch, nullptr, &t, dfoe.as<double>(),
+                   dphi.as<double>(), dmf.as<uint8_t>(), dmd.as<uint8_t>(), max_phi ? c->u64_scratch : nullptr, nullptr, nullptr,
+                   nullptr));
+    // the kernel stores the float32 angles widened to double (one phi layout for both arithmetic types): narrow them back, exactly
+    std::vector<double> wide;
+    if (phi) { wide.resize(n); CHK(download(c, wide.data(), dphi.p, n * sizeof(double))); }
+    if (mask_fixed) CHK(download(c, mask_fixed, dmf.p, n));
+    if (mask_dyn) CHK(download(c, mask_dyn, dmd.p, n));
+    std::vector<double> mx(max_phi ? batch : 0);
+    if (max_phi) CHK(download(c, mx.data(), c->u64_scratch, sizeof(double) * batch));
+    CHK(mav_sync(c));
+    if (phi) for (size_t i = 0; i < n; i++) phi[i] = (float)wide[i];
+    if (max_phi) for (int b = 0; b < batch; b++) max_phi[b] = (float)mx[b];
+    return MAV_OK;
+}
+
 extern "C" int mav_bbox(mav_ctx* c, const uint8_t* img, int batch, int32_t* box)
 {
     CHK(check_batch(c, batch, "mav_bbox"));
     if (!img || !box) return fail(MAV_ERR_ARG, "mav_bbox: NULL argument");
     DevBuf di, db;
-    CHK(di.upload(c, img, c->n0 * batch)); CHK(db.alloc(sizeof(int32_t) * 4 * batch));
+    CHK(di.upload(c, img, c->n0 * batch)); CHK(db.alloc(c, sizeof(int32_t) * 4 * batch));
     launch_box_init(c->stream, c->box_acc, nullptr, batch);
     launch_bbox_u8(c->stream, di.as<uint8_t>(), batch, c->W, c->H, c->i32_scratch, c->box_acc);
     launch_box_finalize(c->stream, c->box_acc, batch, db.as<int32_t>());
@@ -792,7 +916,7 @@ extern "C" int mav_bgr2gray(mav_ctx* c, const uint8_t* bgr, int batch, uint8_t* 
     if (!bgr || !gray) return fail(MAV_ERR_ARG, "mav_bgr2gray: NULL argument");
     const size_t n = c->n0 * batch;
     DevBuf di, dg;
-    CHK(di.upload(c, bgr, 3 * n)); CHK(dg.alloc(n));
+    CHK(di.upload(c, bgr, 3 * n)); CHK(dg.alloc(c, n));
     launch_bgr2gray(c->stream, di.as<uint8_t>(), n, dg.as<uint8_t>());
     CHK(check_launch("bgr2gray"));
     CHK(download(c, gray, dg.p, n));
@@ -818,7 +942,7 @@ extern "C" int mav_window_max(mav_ctx* c, const uint8_t* img, int batch, int64_t
     CHK(check_batch(c, batch, "mav_window_max"));
     if (!img || !out) return fail(MAV_ERR_ARG, "mav_window_max: NULL argument");
     DevBuf di, dout;
-    CHK(di.upload(c, img, c->n0 * batch)); CHK(dout.alloc(sizeof(int64_t) * 3 * batch));
+    CHK(di.upload(c, img, c->n0 * batch)); CHK(dout.alloc(c, sizeof(int64_t) * 3 * batch));
     launch_window_max(c->stream, di.as<uint8_t>(), batch, c->W, c->H, c->u64_scratch, dout.as<int64_t>());
     CHK(check_launch("window_max"));
     CHK(download(c, out, dout.p, sizeof(int64_t) * 3 * batch));
@@ -908,7 +1032,7 @@ extern "C" int mav_analyze_pyramid(mav_ctx* c, const uint8_t* img, int batch, do
     CHK(pyr_plan(c, scale, c->max_batch, &p));
     CHK(ensure_pyr_ws(c, p));
     DevBuf di, dout;
-    CHK(di.upload(c, img, c->n0 * batch)); CHK(dout.alloc(sizeof(int64_t) * 6 * batch));
+    CHK(di.upload(c, img, c->n0 * batch)); CHK(dout.alloc(c, sizeof(int64_t) * 6 * batch));
     HIPCHK(hipMemsetAsync(c->u64_scratch, 0, sizeof(unsigned long long) * batch, c->stream));
     build_pyramid(c, p, di.as<uint8_t>(), batch, p.n - 1);
     for (int l = 0; l < p.n; l++)
@@ -945,7 +1069,7 @@ extern "C" int mav_optimize_window(mav_ctx* c, const uint8_t* img, int batch, co
         return fail(MAV_ERR_OOM, "summed-area tables");
     DevBuf di, dw, ds, dwo;
     CHK(di.upload(c, img, c->n0 * batch)); CHK(dw.upload(c, window_in, sizeof(int32_t) * 4 * batch));
-    CHK(ds.alloc(sizeof(int64_t) * batch)); CHK(dwo.alloc(sizeof(int32_t) * 4 * batch));
+    CHK(ds.alloc(c, sizeof(int64_t) * batch)); CHK(dwo.alloc(c, sizeof(int32_t) * 4 * batch));
     launch_optimize_window(c->stream, di.as<uint8_t>(), batch, c->W, c->H, c->sat, dw.as<int32_t>(), ds.as<int64_t>(), dwo.as<int32_t>());
     CHK(check_launch("optimize_window"));
     CHK(download(c, score, ds.p, sizeof(int64_t) * batch));
@@ -953,48 +1077,70 @@ extern "C" int mav_optimize_window(mav_ctx* c, const uint8_t* img, int batch, co
     return mav_sync(c);
 }
 
-extern "C" int mav_tpr_fpr_counts(mav_ctx* c, const uint8_t* gt, const uint8_t* mask, int batch, int64_t* counts)
+extern "C" int mav_tpr_fpr_counts(mav_ctx* c, const uint8_t* gt, const uint8_t* mask, int mask_value, int batch, int64_t* counts)
 {
     CHK(check_batch(c, batch, "mav_tpr_fpr_counts"));
     if (!gt || !mask || !counts) return fail(MAV_ERR_ARG, "mav_tpr_fpr_counts: NULL argument");
+    if (mask_value < 1 || mask_value > 65535) return fail(MAV_ERR_ARG, "mav_tpr_fpr_counts: mask_value %d outside [1, 65535]", mask_value);
     DevBuf dg, dm;
     CHK(dg.upload(c, gt, c->n0 * batch)); CHK(dm.upload(c, mask, c->n0 * batch));
-    launch_tpr_fpr(c->stream, dg.as<uint8_t>(), dm.as<uint8_t>(), batch, c->W, c->H, c->u64_scratch);
+    launch_tpr_fpr(c->stream, dg.as<uint8_t>(), dm.as<uint8_t>(), (unsigned)mask_value, batch, c->W, c->H, c->u64_scratch);
     CHK(check_launch("tpr_fpr"));
     CHK(download(c, counts, c->u64_scratch, sizeof(int64_t) * 4 * batch));
     return mav_sync(c);
 }
 
-extern "C" int mav_process_batch(mav_ctx* c, const uint8_t* prev, const uint8_t* next, const uint32_t* samples, const double* omega,
-                                 const double* dt, const uint8_t* sky, int batch, const mav_foe_params* fp, const mav_thr_params* tp,
-                                 float* flow, double* phi, uint8_t* mask_fixed, uint8_t* mask_dyn, mav_result* results)
+// frames (mav_process_batch) or a float32 flow field (mav_detect) in, masks and records out: one body for both
+static int process_host(mav_ctx* c, const char* fn, const uint8_t* prev, const uint8_t* next, const float* flow_in,
+                        const uint32_t* samples, const double* omega, const double* dt, const uint8_t* frame0, const uint8_t* sky,
+                        int batch, const mav_foe_params* fp, const mav_thr_params* tp, float* flow_out, double* phi,
+                        uint8_t* mask_fixed, uint8_t* mask_dyn, mav_result* results)
 {
-    CHK(check_batch(c, batch, "mav_process_batch"));
-    if (!prev || !next || !samples || !results) return fail(MAV_ERR_ARG, "mav_process_batch: NULL argument");
+    CHK(check_batch(c, batch, fn));
+    if ((!flow_in && (!prev || !next)) || !samples || !results) return fail(MAV_ERR_ARG, "%s: NULL argument", fn);
     mav_foe_params f;
     if (fp) f = *fp; else mav_foe_defaults(&f);
     if (f.n_pairs < 1 || f.n_pairs > 4096) return fail(MAV_ERR_ARG, "n_pairs %d outside [1, 4096]", f.n_pairs);
     const size_t n = c->n0 * batch;
-    DevBuf dp, dn, ds, dsky, dflow, dphi, dmf, dmd, dres, dom, ddt;
-    CHK(dp.upload(c, prev, n)); CHK(dn.upload(c, next, n));
+    DevBuf dp, dn, ds, dflow, dres, dmf, dmd, dsky, dom, ddt, df0, dphi;      // the always-present buffers take the first blocks
+    if (flow_in) CHK(dflow.upload(c, flow_in, n * 2 * sizeof(float)));
+    else { CHK(dp.upload(c, prev, n)); CHK(dn.upload(c, next, n)); CHK(dflow.alloc(c, n * 2 * sizeof(float))); }
     CHK(ds.upload(c, samples, sizeof(uint32_t) * 4 * (size_t)f.n_pairs * batch));
+    CHK(dres.alloc(c, sizeof(mav_result) * batch));
+    if (mask_fixed) CHK(dmf.alloc(c, n));
+    if (mask_dyn) CHK(dmd.alloc(c, n));
     if (sky) CHK(dsky.upload(c, sky, n));
     if (omega) CHK(dom.upload(c, omega, sizeof(double) * 3 * batch));
     if (omega && dt) CHK(ddt.upload(c, dt, sizeof(double) * batch));
-    CHK(dflow.alloc(n * 2 * sizeof(float)));
-    if (phi) CHK(dphi.alloc(n * sizeof(double)));
-    if (mask_fixed) CHK(dmf.alloc(n));
-    if (mask_dyn) CHK(dmd.alloc(n));
-    CHK(dres.alloc(sizeof(mav_result) * batch));
-    CHK(mav_process_batch_dev(c, dp.as<uint8_t>(), dn.as<uint8_t>(), ds.as<uint32_t>(), dom.as<double>(), ddt.as<double>(),
-                              dsky.as<uint8_t>(), batch, &f, tp, dflow.as<float>(), dphi.as<double>(), dmf.as<uint8_t>(),
-                              dmd.as<uint8_t>(), dres.as<mav_result>()));
-    if (flow) CHK(download(c, flow, dflow.p, n * 2 * sizeof(float)));
+    if (frame0) CHK(df0.upload(c, frame0, batch));
+    if (phi) CHK(dphi.alloc(c, n * sizeof(double)));
+    if (!flow_in) CHK(mav_farneback_dev(c, dp.as<uint8_t>(), dn.as<uint8_t>(), batch, dflow.as<float>()));
+    CHK(mav_detect_dev(c, dflow.as<float>(), ds.as<uint32_t>(), dom.as<double>(), ddt.as<double>(), df0.as<uint8_t>(),
+                       dsky.as<uint8_t>(), batch, &f, tp, dphi.as<double>(), dmf.as<uint8_t>(), dmd.as<uint8_t>(), dres.as<mav_result>()));
+    if (flow_out) CHK(download(c, flow_out, dflow.p, n * 2 * sizeof(float)));
     if (phi) CHK(download(c, phi, dphi.p, n * sizeof(double)));
     if (mask_fixed) CHK(download(c, mask_fixed, dmf.p, n));
     if (mask_dyn) CHK(download(c, mask_dyn, dmd.p, n));
     CHK(download(c, results, dres.p, sizeof(mav_result) * batch));
     return mav_sync(c);
+}
+
+extern "C" int mav_process_batch(mav_ctx* c, const uint8_t* prev, const uint8_t* next, const uint32_t* samples, const double* omega,
+                                 const double* dt, const uint8_t* frame0, const uint8_t* sky, int batch, const mav_foe_params* fp,
+                                 const mav_thr_params* tp, float* flow, double* phi, uint8_t* mask_fixed, uint8_t* mask_dyn,
+                                 mav_result* results)
+{
+    return process_host(c, "mav_process_batch", prev, next, nullptr, samples, omega, dt, frame0, sky, batch, fp, tp, flow, phi,
+                        mask_fixed, mask_dyn, results);
+}
+
+extern "C" int mav_detect(mav_ctx* c, const float* flow, const uint32_t* samples, const double* omega, const double* dt,
+                          const uint8_t* frame0, const uint8_t* sky, int batch, const mav_foe_params* fp, const mav_thr_params* tp,
+                          double* phi, uint8_t* mask_fixed, uint8_t* mask_dyn, mav_result* results)
+{
+    if (!flow) return fail(MAV_ERR_ARG, "mav_detect: NULL flow");
+    return process_host(c, "mav_detect", nullptr, nullptr, flow, samples, omega, dt, frame0, sky, batch, fp, tp, nullptr, phi,
+                        mask_fixed, mask_dyn, results);
 }
 
 // ---- stage hooks -------------------------------------------------------------------------------------------------
@@ -1003,9 +1149,56 @@ static int layer_of(mav_ctx* c, int k, const Layer** l)
     if (!c) return fail(MAV_ERR_ARG, "NULL context");
     if (k < 0 || k >= (int)c->layers.size()) return fail(MAV_ERR_ARG, "layer %d out of range", k);
     HIPCHK(hipSetDevice(c->device));
+    c->scratch_next = 0;
     *l = &c->layers[k];
     return MAV_OK;
 }
+extern "C" int mav_stage_phi_mask(mav_ctx* c, const float* flow, const double* foe, const double* omega, const double* dt,
+                                  const uint8_t* sky, int batch, const mav_thr_params* tp, double* phi, uint8_t* mask_fixed,
+                                  uint8_t* mask_dyn, int32_t* box)
+{
+    CHK(check_batch(c, batch, "mav_stage_phi_mask"));
+    if (!flow || !foe) return fail(MAV_ERR_ARG, "mav_stage_phi_mask: NULL argument");
+    const size_t n = c->n0 * batch;
+    mav_thr_params t;
+    if (tp) t = *tp; else mav_thr_defaults(&t);
+    DevBuf df, dfoe, dsky, dphi, dmf, dmd, dbox;
+    CHK(df.upload(c, flow, n * 2 * sizeof(float)));
+    CHK(dfoe.upload(c, foe, sizeof(double) * 2 * batch));
+    if (sky) CHK(dsky.upload(c, sky, n));
+    if (phi) CHK(dphi.alloc(c, n * sizeof(double)));
+    if (mask_fixed) CHK(dmf.alloc(c, n));
+    if (mask_dyn) CHK(dmd.alloc(c, n));
+    if (box) CHK(dbox.alloc(c, sizeof(int32_t) * 4 * batch));
+    const DerotParams* derot = nullptr;
+    CHK(upload_derot(c, omega, dt, nullptr, batch, true, &derot));
+    CHK(detect_dev(c, df.as<float>(), nullptr, derot, nullptr, dsky.as<uint8_t>(), batch, nullptr, &t, dfoe.as<double>(),
+                   dphi.as<double>(), dmf.as<uint8_t>(), dmd.as<uint8_t>(), nullptr, nullptr, nullptr, dbox.as<int32_t>()));
+    if (phi) CHK(download(c, phi, dphi.p, n * sizeof(double)));
+    if (mask_fixed) CHK(download(c, mask_fixed, dmf.p, n));
+    if (mask_dyn) CHK(download(c, mask_dyn, dmd.p, n));
+    if (box) CHK(download(c, box, dbox.p, sizeof(int32_t) * 4 * batch));
+    return mav_sync(c);
+}
+
+extern "C" int mav_stage_coefficients(mav_ctx* c, int k, float* g, float* xg, float* xxg, float* ig, float* blur_taps)
+{
+    if (!c) return fail(MAV_ERR_ARG, "mav_stage_coefficients: NULL context");
+    const int n = c->pc.n;
+    for (int i = 0; i <= n; i++) {
+        if (g) g[i] = c->pc.g[i];
+        if (xg) xg[i] = c->pc.xg[i];
+        if (xxg) xxg[i] = c->pc.xxg[i];
+    }
+    if (ig) { ig[0] = c->pc.ig11; ig[1] = c->pc.ig03; ig[2] = c->pc.ig33; ig[3] = c->pc.ig55; }
+    if (blur_taps) {
+        const Layer* l;
+        CHK(layer_of(c, k, &l));
+        HIPCHK(hipMemcpy(blur_taps, l->g, sizeof(float) * l->ksize, hipMemcpyDeviceToHost));   // what the kernels actually read
+    }
+    return MAV_OK;
+}
+
 extern "C" int mav_stage_blur_resize(mav_ctx* c, const uint8_t* img, int k, float* out)
 {
     const Layer* l;
@@ -1013,7 +1206,7 @@ extern "C" int mav_stage_blur_resize(mav_ctx* c, const uint8_t* img, int k, floa
     if (!img || !out) return fail(MAV_ERR_ARG, "mav_stage_blur_resize: NULL argument");
     const size_t n = (size_t)l->w * l->h;
     DevBuf di, dout;
-    CHK(di.upload(c, img, c->n0)); CHK(dout.alloc(n * sizeof(float)));
+    CHK(di.upload(c, img, c->n0)); CHK(dout.alloc(c, n * sizeof(float)));
     launch_blur_resize(c->stream, di.as<uint8_t>(), c->n0, 1, c->W, c->H, l->w, l->h, blur_of(c, *l), c->Htmp, c->htmp_stride,
                        dout.as<float>(), n);
     CHK(check_launch("blur_resize"));
@@ -1027,7 +1220,7 @@ extern "C" int mav_stage_polyexp(mav_ctx* c, const float* I, int k, float* R)
     if (!I || !R) return fail(MAV_ERR_ARG, "mav_stage_polyexp: NULL argument");
     const size_t n = (size_t)l->w * l->h;
     DevBuf di, dr;
-    CHK(di.upload(c, I, n * sizeof(float))); CHK(dr.alloc(5 * n * sizeof(float)));
+    CHK(di.upload(c, I, n * sizeof(float))); CHK(dr.alloc(c, 5 * n * sizeof(float)));
     launch_polyexp(c->stream, di.as<float>(), n, 1, l->w, l->h, c->pc, dr.as<float>(), 5 * n);
     CHK(check_launch("polyexp"));
     CHK(download(c, R, dr.p, 5 * n * sizeof(float)));
@@ -1041,7 +1234,7 @@ extern "C" int mav_stage_update_matrices(mav_ctx* c, const float* R0, const floa
     const size_t n = (size_t)l->w * l->h;
     DevBuf d0, d1, df, dm;
     CHK(d0.upload(c, R0, 5 * n * sizeof(float))); CHK(d1.upload(c, R1, 5 * n * sizeof(float)));
-    CHK(df.upload(c, flow, 2 * n * sizeof(float))); CHK(dm.alloc(5 * n * sizeof(float)));
+    CHK(df.upload(c, flow, 2 * n * sizeof(float))); CHK(dm.alloc(c, 5 * n * sizeof(float)));
     launch_update_matrices_flow(c->stream, d0.as<float>(), d1.as<float>(), 5 * n, df.as<float>(), 2 * n, 1, l->w, l->h, dm.as<float>(), 5 * n);
     CHK(check_launch("update_matrices"));
     CHK(download(c, M, dm.p, 5 * n * sizeof(float)));
@@ -1055,7 +1248,7 @@ extern "C" int mav_stage_blur_iter(mav_ctx* c, const float* R0, const float* R1,
     const size_t n = (size_t)l->w * l->h;
     DevBuf d0, d1, dm, dmo, df;
     CHK(d0.upload(c, R0, 5 * n * sizeof(float))); CHK(d1.upload(c, R1, 5 * n * sizeof(float)));
-    CHK(dm.upload(c, M, 5 * n * sizeof(float))); CHK(dmo.alloc(5 * n * sizeof(float))); CHK(df.alloc(2 * n * sizeof(float)));
+    CHK(dm.upload(c, M, 5 * n * sizeof(float))); CHK(dmo.alloc(c, 5 * n * sizeof(float))); CHK(df.alloc(c, 2 * n * sizeof(float)));
     launch_blur_iter(c->stream, dm.as<float>(), dmo.as<float>(), 5 * n, d0.as<float>(), d1.as<float>(), 5 * n, 1, l->w, l->h,
                      c->fb.winsize, update, 1, df.as<float>(), 2 * n);
     CHK(check_launch("blur_iter"));

@@ -26,9 +26,14 @@ struct BlurParams {
     double scale_y;      // H / h
 };
 
+// How the detection kernels treat one pair's float32 flow (what numpy does with it in the reference):
+//   PROMOTE   frame index >= 1 with zero rates: flow - 0.0 is the float32 field promoted to double, double arithmetic after it
+//   DEROTATE  frame index >= 1: Detector.derotate (detector.py:83-117) in double, evaluated on the fly
+//   FRAME0    frame index 0: derotate returns the float32 array itself (detector.py:80-81), float32 arithmetic after it
+enum { MAV_PAIR_PROMOTE = 0, MAV_PAIR_DEROTATE = 1, MAV_PAIR_FRAME0 = 2 };
 struct DerotParams {  // one pair; Detector.derotate
     double o0, o1, o2, sx, sy;  // sx = w*dt/2, sy = h*dt/2
-    int enabled;
+    int mode;                   // MAV_PAIR_*
 };
 
 // ---- flow kernels (kernels_flow.hip) ----------------------------------------------------------------------
@@ -48,6 +53,7 @@ void launch_blur_iter(hipStream_t st, const float* M_in, float* M_out, size_t M_
                       size_t R_stride, int G, int w, int h, int winsize, int do_update, int store_flow, float* flow, size_t f_stride);
 // store_flow == 0: the sweep's flow is consumed inside the kernel only (valid when do_update != 0)
 size_t blur_iter_lds_bytes(int winsize);
+const char* blur_iter_prepare(int winsize);   // grants the general sweep kernel its dynamic LDS on the current device
 bool launch_sweep_rc(hipStream_t st, int mode, const float* fin, size_t fin_stride, int pw, int ph, float mul, const float* R0,
                      const float* R1, size_t R_stride, int G, int w, int h, int winsize, float* fout, size_t fout_stride);
 
@@ -59,7 +65,8 @@ struct FoeScratch {
 };
 // FlowT = float (optionally derotated on the fly) or double (already derotated).
 void launch_foe_f32(hipStream_t st, const float* flow, const DerotParams* derot /*dev, [B] or null*/, const uint32_t* samples,
-                    int B, int W, int H, int N, double mag2_thr, double dist2_thr, FoeScratch s, double* foe);
+                    int B, int W, int H, int N, double mag2_thr, float mag2_thr_f32 /* frame-0 pairs */, double dist2_thr,
+                    FoeScratch s, double* foe);
 void launch_foe_f64(hipStream_t st, const double* flow, const uint32_t* samples, int B, int W, int H, int N, double mag2_thr,
                     double dist2_thr, FoeScratch s, double* foe);
 // box_acc: [B][4] int32 accumulators (x0 min, y0 min, x1 max, y1 max), initialised by launch_box_init.
@@ -76,11 +83,12 @@ void launch_derotate(hipStream_t st, const float* flow, const DerotParams* derot
 void launch_bbox_u8(hipStream_t st, const uint8_t* img, int B, int W, int H, int* maxv /*[B] scratch*/, int32_t* box_acc);
 void launch_window_max(hipStream_t st, const uint8_t* img, int B, int W, int H, unsigned long long* key /*[B]*/,
                        int64_t* out);
-void launch_tpr_fpr(hipStream_t st, const uint8_t* gt, const uint8_t* mask, int B, int W, int H,
+void launch_tpr_fpr(hipStream_t st, const uint8_t* gt, const uint8_t* mask, unsigned mask_value, int B, int W, int H,
                     unsigned long long* counts /*[B][4]*/);
 void launch_bgr2gray(hipStream_t st, const uint8_t* bgr, size_t n, uint8_t* gray);
 void launch_ransac_only(hipStream_t st, FoeScratch s, int M, int N, double dist2_thr, double* foe);
-void launch_make_derot(hipStream_t st, const double* omega, const double* dt, int B, int W, int H, DerotParams* out);
+void launch_make_derot(hipStream_t st, const double* omega /*null: no rotation*/, const double* dt, const uint8_t* frame0, int B,
+                       int W, int H, DerotParams* out);
 
 // ---- window search (kernels_window.hip, compiled with -ffp-contract=off) -----------------------------------------
 #define MAV_PYR_MAX 32

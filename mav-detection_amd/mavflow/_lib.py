@@ -48,6 +48,8 @@ EXPORTS = [
     "mav_comm_unique_id", "mav_comm_init", "mav_comm_destroy", "mav_allgather_results", "mav_stage_blur_resize",
     "mav_stage_polyexp", "mav_stage_update_matrices", "mav_stage_blur_iter",
     "mav_analyze_pyramid", "mav_pyramid_levels", "mav_pyramid_dims", "mav_optimize_window", "mav_stage_pyramid_level",
+    "mav_detect", "mav_detect_dev", "mav_last_flow_dev", "mav_foe_dense_f32", "mav_phi_mask_f32", "mav_stage_coefficients",
+    "mav_stage_phi_mask",
 ]
 
 _lib = None
@@ -63,9 +65,10 @@ def load() -> C.CDLL:
     lib = C.CDLL(SO_PATH)
     lib.mav_last_error.restype = C.c_char_p
     lib.mav_stream.restype = C.c_void_p
+    lib.mav_last_flow_dev.restype = C.c_void_p
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if name not in ("mav_last_error", "mav_stream", "mav_fb_defaults", "mav_foe_defaults", "mav_thr_defaults"):
+        if name not in ("mav_last_error", "mav_stream", "mav_fb_defaults", "mav_foe_defaults", "mav_thr_defaults", "mav_last_flow_dev"):
             fn.restype = C.c_int
     lib.mav_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(FbParams)]
     lib.mav_destroy.argtypes = [C.c_void_p]
@@ -82,15 +85,25 @@ def load() -> C.CDLL:
     lib.mav_phi_mask.argtypes = [vp, vp, vp, vp, C.c_int, C.POINTER(ThrParams), vp, vp, vp, vp]
     lib.mav_bbox.argtypes = [vp, vp, C.c_int, vp]
     lib.mav_window_max.argtypes = [vp, vp, C.c_int, vp]
-    lib.mav_tpr_fpr_counts.argtypes = [vp, vp, vp, C.c_int, vp]
+    lib.mav_tpr_fpr_counts.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp]
     lib.mav_analyze_pyramid.argtypes = [vp, vp, C.c_int, C.c_double, vp]
     lib.mav_pyramid_levels.argtypes = [vp, C.c_double]
     lib.mav_pyramid_dims.argtypes = [vp, C.c_double, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.mav_optimize_window.argtypes = [vp, vp, C.c_int, vp, vp, vp]
     lib.mav_stage_pyramid_level.argtypes = [vp, vp, C.c_double, C.c_int, vp]
-    pb = [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.POINTER(FoeParams), C.POINTER(ThrParams), vp, vp, vp, vp, vp]
+    # ctx, prev, next, samples, omega, dt, frame0, sky, batch, foe params, thr params, flow, phi, mask_fixed, mask_dyn, results
+    pb = [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.POINTER(FoeParams), C.POINTER(ThrParams), vp, vp, vp, vp, vp]
     lib.mav_process_batch.argtypes = pb
     lib.mav_process_batch_dev.argtypes = pb
+    # ctx, flow, samples, omega, dt, frame0, sky, batch, foe params, thr params, phi, mask_fixed, mask_dyn, results
+    dt_ = [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.POINTER(FoeParams), C.POINTER(ThrParams), vp, vp, vp, vp]
+    lib.mav_detect.argtypes = dt_
+    lib.mav_detect_dev.argtypes = dt_
+    lib.mav_last_flow_dev.argtypes = [vp]
+    lib.mav_foe_dense_f32.argtypes = [vp, vp, vp, C.c_int, C.POINTER(FoeParams), vp]
+    lib.mav_phi_mask_f32.argtypes = [vp, vp, vp, vp, C.c_int, C.POINTER(ThrParams), vp, vp, vp, vp]
+    lib.mav_stage_coefficients.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
+    lib.mav_stage_phi_mask.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.POINTER(ThrParams), vp, vp, vp, vp]
     lib.mav_sync.argtypes = [vp]
     lib.mav_stream.argtypes = [vp]
     lib.mav_dev_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
@@ -285,14 +298,20 @@ class Context:
         return out
 
     def foe_dense(self, flow, samples, params: FoeParams | None = None) -> np.ndarray:
-        flow = np.asarray(flow, np.float64)
+        """get_FOE_dense + ransac.  The arithmetic follows the array's dtype as numpy's does in the reference: a float32
+        field (frame index 0, never derotated) has its |flow2| gate evaluated in float32, anything else runs in double."""
+        flow = np.asarray(flow)
+        f32 = flow.dtype == np.float32
+        if not f32:
+            flow = np.asarray(flow, np.float64)
         flow = flow[None] if flow.ndim == 3 else flow
         B = flow.shape[0]
         p = params or foe_defaults()
-        flow = _arr(flow, np.float64, (B, self.H, self.W, 2), "flow")
+        flow = _arr(flow, flow.dtype, (B, self.H, self.W, 2), "flow")
         samples = _arr(np.asarray(samples).reshape(B, 2 * p.n_pairs, 2), np.uint32)
         foe = np.empty((B, 2), np.float64)
-        check(self.lib.mav_foe_dense(self.h, _ptr(flow), _ptr(samples), B, C.byref(p), _ptr(foe)))
+        fn = self.lib.mav_foe_dense_f32 if f32 else self.lib.mav_foe_dense
+        check(fn(self.h, _ptr(flow), _ptr(samples), B, C.byref(p), _ptr(foe)))
         return foe
 
     def ransac(self, estimates, ransac_threshold: float = 30.0):
@@ -310,19 +329,24 @@ class Context:
         return gray
 
     def phi_mask(self, flow, foe, sky=None, params: ThrParams | None = None, want_phi=True):
-        flow = np.asarray(flow, np.float64)
+        """get_phi + the threshold block.  dtype in = dtype of the arithmetic and of phi, as in the reference: float32 flow
+        (frame index 0) -> float32 phi, float64 flow -> float64 phi."""
+        flow = np.asarray(flow)
+        f32 = flow.dtype == np.float32
+        ft = np.float32 if f32 else np.float64
+        flow = np.asarray(flow, ft)
         flow = flow[None] if flow.ndim == 3 else flow
         B = flow.shape[0]
-        flow = _arr(flow, np.float64, (B, self.H, self.W, 2), "flow")
+        flow = _arr(flow, ft, (B, self.H, self.W, 2), "flow")
         foe = _arr(np.asarray(foe, np.float64).reshape(B, 2), np.float64)
         sky = None if sky is None else _arr(np.asarray(sky).reshape(B, self.H, self.W).astype(np.uint8), np.uint8)
         p = params or thr_defaults()
-        phi = np.empty((B, self.H, self.W), np.float64) if want_phi else None
+        phi = np.empty((B, self.H, self.W), ft) if want_phi else None
         mf = np.empty((B, self.H, self.W), np.uint8)
         md = np.empty((B, self.H, self.W), np.uint8)
-        mx = np.empty(B, np.float64) if want_phi else None      # max(phi) needs the exact path, like phi itself
-        check(self.lib.mav_phi_mask(self.h, _ptr(flow), _ptr(foe), _ptr(sky), B, C.byref(p), _ptr(phi), _ptr(mf),
-                                    _ptr(md), _ptr(mx)))
+        mx = np.empty(B, ft) if want_phi else None      # max(phi) needs the exact path, like phi itself
+        fn = self.lib.mav_phi_mask_f32 if f32 else self.lib.mav_phi_mask
+        check(fn(self.h, _ptr(flow), _ptr(foe), _ptr(sky), B, C.byref(p), _ptr(phi), _ptr(mf), _ptr(md), _ptr(mx)))
         return phi, mf.view(np.bool_), md.view(np.bool_), mx
 
     def bbox(self, img) -> np.ndarray:
@@ -374,45 +398,104 @@ class Context:
         check(self.lib.mav_optimize_window(self.h, _ptr(img), B, _ptr(win), _ptr(score), _ptr(out)))
         return score, out
 
-    def tpr_fpr_counts(self, gt, mask) -> np.ndarray:
+    def tpr_fpr_counts(self, gt, mask, mask_value: int = 255) -> np.ndarray:
+        """(batch, 4) = positives, negatives, true positives, false positives of calculate_tpr_fpr(gt, mask_value * mask)."""
         gt = self._imgs(gt, "gt")
         mask = self._imgs(np.asarray(mask).astype(np.uint8), "mask")
         out = np.empty((gt.shape[0], 4), np.int64)
-        check(self.lib.mav_tpr_fpr_counts(self.h, _ptr(gt), _ptr(mask), gt.shape[0], _ptr(out)))
+        check(self.lib.mav_tpr_fpr_counts(self.h, _ptr(gt), _ptr(mask), int(mask_value), gt.shape[0], _ptr(out)))
         return out
 
+    def _detect_args(self, B, samples, omega, dt, frame0, sky, fp):
+        samples = _arr(np.asarray(samples).reshape(B, 2 * fp.n_pairs, 2), np.uint32)
+        omega = None if omega is None else _arr(np.asarray(omega, np.float64).reshape(B, 3), np.float64)
+        dt = None if dt is None else _arr(np.asarray(dt, np.float64).reshape(B), np.float64)
+        frame0 = None if frame0 is None else _arr(np.asarray(frame0).reshape(B).astype(np.uint8), np.uint8)
+        sky = None if sky is None else _arr(np.asarray(sky).reshape(B, self.H, self.W).astype(np.uint8), np.uint8)
+        return samples, omega, dt, frame0, sky
+
     def process_batch(self, prev, nxt, samples, omega=None, dt=None, sky=None, foe_params=None, thr_params=None,
-                      want_flow=True, want_phi=False, want_masks=True):
-        """Fused loop body of Processor.run_detection (processor.py:305-341) for a batch of pairs."""
+                      want_flow=True, want_phi=False, want_masks=True, frame0=None):
+        """Fused loop body of Processor.run_detection (processor.py:305-341) for a batch of pairs.  frame0: per-pair flags of
+        the reference's frame index 0 (no derotation, float32 arithmetic; detector.py:80-81)."""
         prev, nxt = self._imgs(prev, "prev"), self._imgs(nxt, "next")
         B = prev.shape[0]
         fp = foe_params or foe_defaults()
         tp = thr_params or thr_defaults()
-        samples = _arr(np.asarray(samples).reshape(B, 2 * fp.n_pairs, 2), np.uint32)
-        omega = None if omega is None else _arr(np.asarray(omega, np.float64).reshape(B, 3), np.float64)
-        dt = None if dt is None else _arr(np.asarray(dt, np.float64).reshape(B), np.float64)
-        sky = None if sky is None else _arr(np.asarray(sky).reshape(B, self.H, self.W).astype(np.uint8), np.uint8)
+        samples, omega, dt, frame0, sky = self._detect_args(B, samples, omega, dt, frame0, sky, fp)
         flow = np.empty((B, self.H, self.W, 2), np.float32) if want_flow else None
         phi = np.empty((B, self.H, self.W), np.float64) if want_phi else None
         mf = np.empty((B, self.H, self.W), np.uint8) if want_masks else None
         md = np.empty((B, self.H, self.W), np.uint8) if want_masks else None
         res = np.empty(B, RESULT_DTYPE)
-        check(self.lib.mav_process_batch(self.h, _ptr(prev), _ptr(nxt), _ptr(samples), _ptr(omega), _ptr(dt), _ptr(sky),
+        check(self.lib.mav_process_batch(self.h, _ptr(prev), _ptr(nxt), _ptr(samples), _ptr(omega), _ptr(dt), _ptr(frame0), _ptr(sky),
                                          B, C.byref(fp), C.byref(tp), _ptr(flow), _ptr(phi), _ptr(mf), _ptr(md), _ptr(res)))
         return dict(flow=flow, phi=phi, mask_fixed=None if mf is None else mf.view(np.bool_),
+                    mask_dyn=None if md is None else md.view(np.bool_), results=res)
+
+    def detect(self, flow, samples, omega=None, dt=None, sky=None, foe_params=None, thr_params=None, want_phi=False,
+               want_masks=True, frame0=None):
+        """processor.py:305-341 from the reference's own flow seam: a float32 (B, H, W, 2) field (Dataset.get_flow_uv) in,
+        derotation -> FoE -> phi -> masks -> box on the device, masks and records out."""
+        flow = np.asarray(flow, np.float32)
+        flow = flow[None] if flow.ndim == 3 else flow
+        B = flow.shape[0]
+        flow = _arr(flow, np.float32, (B, self.H, self.W, 2), "flow")
+        fp = foe_params or foe_defaults()
+        tp = thr_params or thr_defaults()
+        samples, omega, dt, frame0, sky = self._detect_args(B, samples, omega, dt, frame0, sky, fp)
+        phi = np.empty((B, self.H, self.W), np.float64) if want_phi else None
+        mf = np.empty((B, self.H, self.W), np.uint8) if want_masks else None
+        md = np.empty((B, self.H, self.W), np.uint8) if want_masks else None
+        res = np.empty(B, RESULT_DTYPE)
+        check(self.lib.mav_detect(self.h, _ptr(flow), _ptr(samples), _ptr(omega), _ptr(dt), _ptr(frame0), _ptr(sky), B,
+                                  C.byref(fp), C.byref(tp), _ptr(phi), _ptr(mf), _ptr(md), _ptr(res)))
+        return dict(phi=phi, mask_fixed=None if mf is None else mf.view(np.bool_),
                     mask_dyn=None if md is None else md.view(np.bool_), results=res)
 
     # -- device-pointer path (bench, multi-GPU) --------------------------------------------------------------
     def process_batch_dev(self, prev_ptr, next_ptr, samples_ptr, batch, results_ptr, flow_ptr=None, omega_ptr=None,
                           dt_ptr=None, sky_ptr=None, phi_ptr=None, mf_ptr=None, md_ptr=None, foe_params=None,
-                          thr_params=None):
+                          thr_params=None, frame0_ptr=None):
         fp = foe_params or foe_defaults()
         tp = thr_params or thr_defaults()
-        check(self.lib.mav_process_batch_dev(self.h, prev_ptr, next_ptr, samples_ptr, omega_ptr, dt_ptr, sky_ptr, batch,
+        check(self.lib.mav_process_batch_dev(self.h, prev_ptr, next_ptr, samples_ptr, omega_ptr, dt_ptr, frame0_ptr, sky_ptr, batch,
                                              C.byref(fp), C.byref(tp), flow_ptr, phi_ptr, mf_ptr, md_ptr, results_ptr))
+
+    def last_flow(self, pair: int) -> np.ndarray:
+        """Flow field (H, W, 2) float32 of pair `pair` of the most recent process_batch_dev / farneback_dev call, downloaded
+        from wherever that call wrote it (the caller's buffer or the context's workspace)."""
+        p = self.lib.mav_last_flow_dev(self.h)
+        if not p:
+            raise ValueError("no flow has been computed on this context yet")
+        if not 0 <= pair < self.max_batch:
+            raise ValueError(f"pair {pair} outside [0, {self.max_batch})")
+        out = np.empty((self.H, self.W, 2), np.float32)
+        check(self.lib.mav_memcpy_d2h(self.h, _ptr(out), p + pair * out.nbytes, out.nbytes))
+        return out
 
     def farneback_dev(self, prev_ptr, next_ptr, batch, flow_ptr):
         check(self.lib.mav_farneback_dev(self.h, prev_ptr, next_ptr, batch, flow_ptr))
+
+    # -- multi-GPU record exchange (RCCL through the library, on the context's stream) ------------------------
+    def comm_unique_id(self) -> np.ndarray:
+        """A fresh ncclUniqueId (128 bytes, uint8) -- rank 0 creates it, every rank passes the same bytes to comm_init."""
+        uid = np.zeros(128, np.uint8)
+        check(self.lib.mav_comm_unique_id(_ptr(uid)))
+        return uid
+
+    def comm_init(self, uid, rank: int, nranks: int):
+        uid = np.ascontiguousarray(np.asarray(uid, np.uint8).reshape(128))
+        comm = C.c_void_p()
+        check(self.lib.mav_comm_init(self.h, _ptr(uid), int(rank), int(nranks), C.byref(comm)))
+        return comm
+
+    def allgather(self, comm, local_ptr, bytes_per_rank: int, all_ptr):
+        """ncclAllGather of bytes_per_rank bytes from every rank, enqueued on the context's stream (no host sync)."""
+        check(self.lib.mav_allgather_results(self.h, comm, local_ptr, int(bytes_per_rank), all_ptr))
+
+    def comm_destroy(self, comm):
+        check(self.lib.mav_comm_destroy(comm))
 
     def timer_start(self):
         check(self.lib.mav_timer_start(self.h))
@@ -434,6 +517,36 @@ class Context:
         return {names[i].decode(): (ms[i], cnt[i]) for i in range(n.value)}
 
     # -- stage hooks (parity tests) --------------------------------------------------------------------------
+    def stage_phi_mask(self, flow32, foe, omega=None, dt=None, sky=None, params: ThrParams | None = None, want_phi=False):
+        """The phi / mask / box stage of the fused path (float32 flow, double arithmetic, screen on unless phi is wanted)
+        with a caller-supplied FoE."""
+        flow = np.asarray(flow32, np.float32)
+        flow = flow[None] if flow.ndim == 3 else flow
+        B = flow.shape[0]
+        flow = _arr(flow, np.float32, (B, self.H, self.W, 2), "flow")
+        foe = _arr(np.asarray(foe, np.float64).reshape(B, 2), np.float64)
+        omega = None if omega is None else _arr(np.asarray(omega, np.float64).reshape(B, 3), np.float64)
+        dt = None if dt is None else _arr(np.asarray(dt, np.float64).reshape(B), np.float64)
+        sky = None if sky is None else _arr(np.asarray(sky).reshape(B, self.H, self.W).astype(np.uint8), np.uint8)
+        p = params or thr_defaults()
+        phi = np.empty((B, self.H, self.W), np.float64) if want_phi else None
+        mf = np.empty((B, self.H, self.W), np.uint8)
+        md = np.empty((B, self.H, self.W), np.uint8)
+        box = np.empty((B, 4), np.int32)
+        check(self.lib.mav_stage_phi_mask(self.h, _ptr(flow), _ptr(foe), _ptr(omega), _ptr(dt), _ptr(sky), B, C.byref(p), _ptr(phi),
+                                          _ptr(mf), _ptr(md), _ptr(box)))
+        return phi, mf.view(np.bool_), md.view(np.bool_), box
+
+    def stage_coefficients(self, k: int = -1):
+        """The constants the flow kernels use: dict(g, xg, xxg (poly_n + 1 each, centre first), ig = [ig11, ig03, ig33, ig55],
+        blur = layer k's Gaussian taps when k >= 0)."""
+        n = self.fb.poly_n
+        g, xg, xxg = (np.empty(n + 1, np.float32) for _ in range(3))
+        ig = np.empty(4, np.float32)
+        blur = np.empty(self.layer_dims(k)[3], np.float32) if k >= 0 else None
+        check(self.lib.mav_stage_coefficients(self.h, k, _ptr(g), _ptr(xg), _ptr(xxg), _ptr(ig), _ptr(blur)))
+        return dict(g=g, xg=xg, xxg=xxg, ig=ig, blur=blur)
+
     def stage_blur_resize(self, img, k):
         img = _arr(img, np.uint8, (self.H, self.W), "img")
         w, h, _, _ = self.layer_dims(k)

@@ -11,16 +11,6 @@ import numpy as np
 from . import _lib
 
 
-def bgr_to_gray(img: np.ndarray) -> np.ndarray:
-    """cv2.cvtColor(COLOR_BGR2GRAY) on u8: fixed-point (B*1868 + G*9617 + R*4899 + 8192) >> 14.
-    Host form of the formula (used by tests as the checker of mav_bgr2gray); the class below converts on the GPU."""
-    a = np.asarray(img)
-    if a.ndim == 2:
-        return np.ascontiguousarray(a, np.uint8)
-    b, g, r = (a[..., i].astype(np.uint32) for i in range(3))
-    return ((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14).astype(np.uint8)
-
-
 def flow_to_hsv(flow: np.ndarray):
     """The HSV image the reference composes from a flow field (farneback.py:83-94), including its quirks: hue = angle / 2
     in degrees truncated to u8, saturation 255, value = 2 x min-max-normalised magnitude stored into a u8 array (numpy

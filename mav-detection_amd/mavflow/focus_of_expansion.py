@@ -47,25 +47,26 @@ class FocusOfExpansion:
         return im_helpers._ctx(self.flow_width, self.flow_height).ransac(estimates, self.ransac_threshold)
 
     def get_FOE_dense(self, flow_uv: np.ndarray) -> Tuple[float, float]:
-        """FoE from N = 1000 random flow-line intersections + the RANSAC vote.  float32 input is promoted to double
-        (the reference's frame-0 path gates |flow| in float32; the two agree unless |flow2| is within 1e-7 of 2.5)."""
+        """FoE from N = 1000 random flow-line intersections + the RANSAC vote.  The arithmetic follows the array's dtype as
+        numpy's does: a float32 field (frame index 0, which derotate hands back untouched) has its |flow2| gate evaluated in
+        float32, a float64 field in double."""
         N = 1000
         rand1 = np.zeros((N * 2, 2), dtype=np.uint32)
         rand1[..., 0] = np.random.randint(0, flow_uv.shape[0], N * 2)
         rand1[..., 1] = np.random.randint(0, flow_uv.shape[1], N * 2)
-        foe = self._ctx(flow_uv).foe_dense(np.asarray(flow_uv, np.float64), rand1, self._foe_params(N))[0]
+        foe = self._ctx(flow_uv).foe_dense(flow_uv, rand1, self._foe_params(N))[0]
         return (float(foe[0]), float(foe[1]))
 
     def get_phi(self, derotated_flow_uv: np.ndarray, FoE: Tuple[float, float]) -> np.ndarray:
-        """Angle (degrees) between each flow vector and the ray from the FoE through its pixel; max goes to .max_flow."""
+        """Angle (degrees) between each flow vector and the ray from the FoE through its pixel; max goes to .max_flow.
+        float32 flow in -> float32 arithmetic and float32 phi out (zeros_like in the reference), float64 otherwise."""
         if FoE[0] is np.nan:                      # identity test, as the reference (:160)
             return np.zeros(0)
-        phi, _, _, mx = self._ctx(derotated_flow_uv).phi_mask(np.asarray(derotated_flow_uv, np.float64), FoE)
+        phi, _, _, mx = self._ctx(derotated_flow_uv).phi_mask(derotated_flow_uv, FoE)
         self.max_flow = mx[0]
         return phi[0]
 
     def get_masks(self, derotated_flow_uv: np.ndarray, FoE: Tuple[float, float], sky_mask=None, params=None):
         """The threshold block of processor.py:333-341 -> (estimate_fixed, total_mask); phi is not materialised."""
-        _, fixed, total, _ = self._ctx(derotated_flow_uv).phi_mask(np.asarray(derotated_flow_uv, np.float64), FoE, sky=sky_mask,
-                                                                  params=params, want_phi=False)
+        _, fixed, total, _ = self._ctx(derotated_flow_uv).phi_mask(derotated_flow_uv, FoE, sky=sky_mask, params=params, want_phi=False)
         return fixed[0], total[0]

@@ -1,6 +1,7 @@
 """The image helpers the hot path names (/root/reference/src/im_helpers.py), on libmavflow where they touch whole frames:
 get_magnitude (:150-159), get_simple_bounding_box (:55-84), calculate_tpr_fpr (:244-252), to_int / to_rgb (:162-200),
-pyramid / sliding_window (:12-52, level 0 only: the upper levels need cv2.resize(INTER_AREA), absent here)."""
+pyramid / sliding_window (:12-52; the levels above 0 are imutils.resize -> cv2.resize(INTER_AREA) restated on the device,
+parity unpinned at the cv2 boundary -- DESIGN.md section 2)."""
 from __future__ import annotations
 
 from typing import Iterator, Tuple
@@ -43,15 +44,26 @@ def get_simple_bounding_box(img: np.ndarray) -> Rectangle:
 
 
 def calculate_tpr_fpr(gt_img: np.ndarray, img: np.ndarray) -> Tuple[float, float]:
-    """TPR / FPR of a detection image against a u8 ground truth.  `img` is 255 * mask in the reference's call sites
-    (processor.py:350-351); any array whose nonzero pixels are 255 (or a bool / 0-1 mask) is accepted."""
+    """TPR / FPR of a detection image against a u8 ground truth, the reference's literal counts (:244-252):
+    tp = sum(gt * img > 127), fp = sum((255 - gt) * img > 127) over positives = sum(gt > 127), negatives = sum(255 - gt > 127).
+    `img` is 255 * mask at the reference's call sites (processor.py:350-351: an int64 image, so gt * img never wraps and
+    gt * 255 > 127 <=> gt >= 1); a bool mask multiplies by 1 (gt * img > 127 <=> gt > 127).  Both forms are counted on the
+    device as numpy would; anything else (other values, or a uint8 image whose product with gt would wrap) is rejected
+    rather than guessed at."""
     gt = np.ascontiguousarray(gt_img, np.uint8)
     m = np.asarray(img)
     mask = (m != 0).astype(np.uint8)
-    if m.dtype != np.bool_ and mask.any() and not np.isin(m[m != 0], (1, 255)).all():
-        raise ValueError("calculate_tpr_fpr: detection image must be a 0/1 mask or 255 * mask")
+    if m.dtype == np.bool_:
+        value = 1
+    else:
+        values = np.unique(m[m != 0])
+        if values.size > 1 or (values.size == 1 and values[0] not in (1, 255)):
+            raise ValueError("calculate_tpr_fpr: detection image must be a bool mask, a 0/1 mask or 255 * mask")
+        value = int(values[0]) if values.size else 1
+        if value == 255 and m.dtype.itemsize == 1:
+            raise ValueError("calculate_tpr_fpr: a uint8 255-image would wrap in gt * img; pass 255 * mask (int) as the reference does")
     H, W = gt.shape
-    pos, neg, tp, fp = (int(v) for v in _ctx(W, H).tpr_fpr_counts(gt, mask)[0])
+    pos, neg, tp, fp = (int(v) for v in _ctx(W, H).tpr_fpr_counts(gt, mask, value)[0])
     with np.errstate(all="ignore"):
         return (np.float64(tp) / np.float64(pos), np.float64(fp) / np.float64(neg))
 
@@ -74,9 +86,27 @@ def to_rgb(img: np.ndarray, max_value: float = None) -> np.ndarray:
 
 
 def pyramid(image: np.ndarray, scale: float = 1.5, minSize: Tuple[int, int] = (30, 30)) -> Iterator[np.ndarray]:
-    """Level 0 only.  The reference's further levels go through imutils.resize -> cv2.resize(INTER_AREA); neither library
-    exists here and nothing pins their output, so they are not reproduced."""
+    """Every level of the reference's generator (:12-35): the image itself, then imutils.resize(previous, width=int(w / scale))
+    = cv2.resize(INTER_AREA) until a side drops below minSize.  Levels >= 1 come from the device (mav_stage_pyramid_level, the
+    same cascade Detector.analyze_pyramid scans), so iterating pyramid() + sliding_window() as the reference does sees exactly
+    the images analyze_pyramid scored.  u8 images with 1 or 3 equal channels (what im_helpers.to_rgb produces); the INTER_AREA
+    arithmetic is a restatement of OpenCV's, unpinned (no cv2 here)."""
+    a = np.asarray(image)
     yield image
+    if a.dtype != np.uint8:
+        raise TypeError("pyramid: u8 image expected (im_helpers.to_rgb output)")
+    if tuple(minSize) != (30, 30):
+        raise ValueError("pyramid: only the reference's minSize (30, 30) is implemented")
+    gray = a
+    if a.ndim == 3:
+        if not (np.array_equal(a[..., 0], a[..., 1]) and np.array_equal(a[..., 0], a[..., 2])):
+            raise ValueError("pyramid: 3-channel input must be a gray replica (im_helpers.to_rgb)")
+        gray = np.ascontiguousarray(a[..., 0])
+    H, W = gray.shape
+    ctx = _ctx(W, H)
+    for level in range(1, len(ctx.pyramid_dims(scale))):
+        lv = ctx.pyramid_level(gray, level, scale)
+        yield np.repeat(lv[..., None], a.shape[2], axis=2) if a.ndim == 3 else lv
 
 
 def sliding_window(image: np.ndarray, stepSize: int, windowSize: Tuple[int, int]):

@@ -123,8 +123,8 @@ class Processor:
             drone_flow_avg_gt = np.average(gt_derotated[segmentation > 127], axis=0)
         center = im_helpers.get_simple_bounding_box(segmentation).get_center()
         r.center_phi = np.rad2deg(np.arctan2(center[1] - r.foe_gt[1], center[0] - r.foe_gt[0]))
-        r.tpr_fixed, r.fpr_fixed = im_helpers.calculate_tpr_fpr(segmentation, estimate_fixed)
-        r.tpr, r.fpr = im_helpers.calculate_tpr_fpr(segmentation, total_mask)
+        r.tpr_fixed, r.fpr_fixed = im_helpers.calculate_tpr_fpr(segmentation, 255 * estimate_fixed)     # as processor.py:350-351
+        r.tpr, r.fpr = im_helpers.calculate_tpr_fpr(segmentation, 255 * total_mask)
         r.sky_tpr, r.sky_fpr = sky_scores
         r.drone_flow_pixels = (drone_flow_avg_gt[0], drone_flow_avg_gt[1])
         r.drone_size_pixels = np.sum(segmentation > 127)
@@ -171,10 +171,9 @@ class Processor:
                 rot = [i >= 1 for i in ids]
                 omega = np.stack([np.asarray(self.dataset.get_angular_difference(i - 1, i), np.float64) / dt
                                   for i, dt in zip(ids, dts)])
-                if not all(rot):                               # frame 0 is never derotated (detector.py:80-81)
-                    omega[[k for k, r_ in enumerate(rot) if not r_]] = 0.0
+                # frame 0 is never derotated and runs in float32 (detector.py:80-81): flagged per pair below
                 sky = np.stack([self.dataset.get_sky_segmentation(i) for i in ids])
-                out = ctx.process_batch(prev, nxt, samples, omega=omega, dt=dts, sky=sky)
+                out = ctx.process_batch(prev, nxt, samples, omega=omega, dt=dts, sky=sky, frame0=[not r_ for r_ in rot])
                 for k, i in enumerate(ids):
                     gt = utils.assert_type(self.dataset.get_gt_of(i))
                     gt_der = self.detector.derotate(i - 1, i, gt)

@@ -231,3 +231,31 @@ def test_overlapped_upload_path(mav):
         c.sync()
         got = df.download(np.float32, ref.shape)
     assert np.array_equal(got, ref)
+
+
+def test_double_buffered_uploads_with_different_content(mav):
+    """The documented deployment pattern -- upload batch k+1 into the other buffer set while batch k computes -- with DIFFERENT
+    frames in every batch: an upload must not overwrite a set that an earlier, still running batch reads (mav_upload_async
+    orders the copy stream behind the compute stream), and a batch must not start before its own upload has landed
+    (mav_upload_fence).  Every batch's flow must equal the synchronous entry point's."""
+    from mavflow import _lib
+    W, H, B, N = 640, 480, 4, 6
+    batches = []
+    for k in range(N):
+        prev, nxt = synth.make_batch(W, H, B, distinct=2)
+        batches.append((np.roll(prev, 17 * k + 3, axis=2), np.roll(nxt, 17 * k + 3, axis=2)))
+    with _lib.Context(W, H, B) as c:
+        ref = [c.farneback(p, n) for p, n in batches]
+        pinned = [(c.pinned_like(p), c.pinned_like(n)) for p, n in batches]
+        sets = [(c.alloc(batches[0][0].nbytes), c.alloc(batches[0][1].nbytes)) for _ in range(2)]
+        outs = [c.alloc(ref[0].nbytes) for _ in range(N)]
+        c.upload_async(sets[0][0], pinned[0][0]); c.upload_async(sets[0][1], pinned[0][1]); c.upload_fence()
+        for k in range(N):
+            cur, nx = sets[k & 1], sets[(k + 1) & 1]
+            if k + 1 < N:                                   # batch k+1 crosses PCIe into the set batch k-1 may still be reading
+                c.upload_async(nx[0], pinned[k + 1][0]); c.upload_async(nx[1], pinned[k + 1][1])
+            c.farneback_dev(cur[0].ptr, cur[1].ptr, B, outs[k].ptr)
+            c.upload_fence()
+        c.sync()
+        for k in range(N):
+            assert np.array_equal(outs[k].download(np.float32, ref[k].shape), ref[k]), k

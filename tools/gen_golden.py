@@ -220,6 +220,122 @@ def main():
     np.savez_compressed(os.path.join(OUT, "foe_chain.npz"), **out)
     print("wrote", os.path.join(OUT, "foe_chain.npz"), {k: getattr(v, "shape", None) for k, v in out.items()})
     window_search(ref_det, ref_im, ref_utils)
+    frame0_and_io(ref_foe, ref_im, ref_lk, ref_utils, ref_det, flows[0].astype(np.float32), foes[0], synth)
+
+
+def _threshold_block(phi, flow_mag, sky):
+    """processor.py:333-341, literally (dtype follows the inputs, as in the reference)."""
+    with np.errstate(all="ignore"):
+        angle_threshold_max = phi > (0.25 + (0.5 + 8 / flow_mag))
+        angle_threshold_min = phi < (0.25 - (0.5 + 8 / flow_mag))
+        angle_threshold = np.logical_or(angle_threshold_min, angle_threshold_max)
+        total_mask = (flow_mag > 0.5) * ~sky * angle_threshold
+        fixed_angle_threshold = 15
+        estimate_fixed = phi * (flow_mag > 1.0) * ~sky > fixed_angle_threshold
+    return estimate_fixed, total_mask
+
+
+def frame0_and_io(ref_foe, ref_im, ref_lk, ref_utils, ref_det, flow32, foe_case0, synth):
+    """tests/golden/frame0_io.npz:
+    (1) the reference's FLOAT32 path -- for frame index 0 Detector.derotate returns the float32 flow itself (detector.py:80-81)
+        and get_FOE_dense's |flow2| gate (:78), get_phi (:163-177) and the threshold block then run in float32;
+    (2) the .flo bytes utils.write_flow produces and what utils.read_flow returns for them (utils.py:204-257);
+    (3) the JSON text processor.py:83-84 writes for a filled FrameResult (utils.get_json, utils.py:350-361)."""
+    import json
+    import tempfile
+    import frame_result as ref_fr
+    out = {}
+    H, W = flow32.shape[:2]
+    assert flow32.dtype == np.float32
+    lk = ref_lk.LucasKanade(np.zeros((H, W, 3), np.uint8))
+    foe = ref_foe.FocusOfExpansion(lk)
+
+    # ---- (1a) phi + masks in float32 --------------------------------------------------------------------------------
+    e = (float(foe_case0[0]), float(foe_case0[1]))
+    phi32 = foe.get_phi(flow32, e)
+    mag32 = ref_im.get_magnitude(flow32)
+    assert phi32.dtype == np.float32 and mag32.dtype == np.float32
+    sky = np.zeros((H, W), dtype=bool)
+    sky[:15, :] = True
+    nosky = np.zeros((H, W), dtype=bool)
+    f_ns, t_ns = _threshold_block(phi32, mag32, nosky)
+    f_s, t_s = _threshold_block(phi32, mag32, sky)
+    out.update(f0_flow=flow32, f0_foe=np.array(e), f0_phi=phi32, f0_mag=mag32, f0_sky=sky, f0_fixed_nosky=f_ns, f0_total_nosky=t_ns,
+               f0_fixed_sky=f_s, f0_total_sky=t_s, f0_max_flow=np.array(foe.max_flow))
+
+    # ---- (1b) the float32 |flow2| gate: a radial field of magnitude 2.5 +- rounding, so that the float32 norm and the double
+    #      norm of the same float32 vector fall on different sides of 2.5 for a fair share of the pixels; every line passes through
+    #      the centre, all candidates tie and RANSAC returns the FIRST one, which depends on which pairs the gate lets through ----
+    yy, xx = np.mgrid[0:H, 0:W]
+    dx, dy = xx - 71.3, yy - 52.9
+    r = np.hypot(dx, dy)
+    gate = (2.5 * np.stack([dx / r, dy / r], axis=-1)).astype(np.float32)
+    m32 = ref_im.get_magnitude(gate)
+    m64 = ref_im.get_magnitude(gate.astype(np.float64))
+    out["f0_gate_disagree_fraction"] = np.array(float(np.mean((m32 < 2.5) != (m64 < 2.5))))
+    seed = None
+    for cand in range(1000, 1400):
+        np.random.seed(cand)
+        a = foe.get_FOE_dense(gate)
+        np.random.seed(cand)
+        b = foe.get_FOE_dense(gate.astype(np.float64))
+        if a != b:
+            seed, f32_foe, f64_foe = cand, a, b
+            break
+    assert seed is not None, "no seed separates the float32 gate from the double gate"
+    out.update(f0_gate_flow=gate, f0_gate_seed=np.array(seed), f0_gate_foe=np.array(f32_foe), f0_gate_foe_if_double=np.array(f64_foe))
+
+    # ---- (1c) whole chain for frame index 0 at 640x480: derotate(-1, 0, f32) is the identity ----------------------------
+    W2, H2 = 640, 480
+    lk2 = ref_lk.LucasKanade(np.zeros((H2, W2, 3), np.uint8))
+    foe2 = ref_foe.FocusOfExpansion(lk2)
+    fl2 = synth.synthetic_flow(W2, H2, seed=3)
+    class _DS:
+        capture_size = (W2, H2)
+        def get_delta_time(self, i): return 1.0 / 30.0
+        def get_angular_difference(self, a, b): return np.array([0.013, -0.021, 0.008])
+    det2 = ref_det.Detector(_DS())
+    der = det2.derotate(-1, 0, fl2)
+    assert der is fl2 and der.dtype == np.float32
+    np.random.seed(1234)
+    e2 = foe2.get_FOE_dense(der)
+    phi2 = foe2.get_phi(der, e2)
+    mag2 = ref_im.get_magnitude(der)
+    fixed2, total2 = _threshold_block(phi2, mag2, np.zeros((H2, W2), dtype=bool))
+    rct = ref_im.get_simple_bounding_box(fixed2)
+    out.update(chain0_foe=np.array(e2), chain0_fixed_bits=np.packbits(fixed2), chain0_total_bits=np.packbits(total2),
+               chain0_phi=phi2, chain0_box=np.array([rct.topleft[0], rct.topleft[1], rct.size[0], rct.size[1]]),
+               chain0_phi_dtype=np.array(str(phi2.dtype)))
+
+    # ---- (2) .flo --------------------------------------------------------------------------------------------------------
+    rng = np.random.default_rng(21)
+    flo = rng.normal(0, 3, (37, 53, 2)).astype(np.float32)
+    flo[0, 0] = (np.float32(1e-30), np.float32(-1e30))
+    with tempfile.TemporaryDirectory() as d:
+        fn = os.path.join(d, "a.flo")
+        ref_utils.write_flow(fn, flo)
+        raw = open(fn, "rb").read()
+        back = ref_utils.read_flow(fn)
+        ref_utils.write_flow(fn, flo[..., 0].astype(np.float64), flo[..., 1].astype(np.float64))     # separate u, v planes
+        raw_uv = open(fn, "rb").read()
+    out.update(flo_in=flo, flo_bytes=np.frombuffer(raw, np.uint8), flo_read=back, flo_bytes_uv=np.frombuffer(raw_uv, np.uint8),
+               flo_read_dtype=np.array(str(back.dtype)))
+
+    # ---- (3) FrameResult -> JSON text (processor.py:83-84) -----------------------------------------------------------------
+    r = ref_fr.FrameResult()
+    r.foe_dense = (np.float64(297.87096720308574), np.float64(222.21492686396977))
+    r.foe_gt = (352.0, 216.0)
+    r.center_phi = np.float64(-143.13010235415598)
+    r.tpr_fixed, r.fpr_fixed = np.float64(0.75), np.float64(0.001953125)
+    r.tpr, r.fpr = np.float64(1.0) / np.float64(3.0), np.float64("nan")
+    r.sky_tpr, r.sky_fpr = (0.0, 0.0)
+    r.drone_flow_pixels = (np.float32(6.0), np.float32(-3.0))
+    r.drone_size_pixels = np.sum(np.ones((24, 24)) > 0)          # a numpy integer, as processor.py:360 produces
+    r.time = 4 * (1 / 30.0)
+    text = json.dumps(ref_utils.get_json(r), indent=4, sort_keys=True)
+    out["json_text"] = np.array(text)
+    np.savez_compressed(os.path.join(OUT, "frame0_io.npz"), **out)
+    print("wrote", os.path.join(OUT, "frame0_io.npz"), "gate seed", seed, "gate disagreement", float(out["f0_gate_disagree_fraction"]))
 
 
 def _blob_image(W, H, seed, blobs):
