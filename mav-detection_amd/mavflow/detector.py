@@ -60,6 +60,25 @@ class Detector:
         W, H = self.dataset.capture_size[0], self.dataset.capture_size[1]
         return im_helpers._ctx(W, H).derotate(np.asarray(flow_uv, np.float32), omega, dt)[0]
 
+    def derotate_at(self, previous_frame_index: int, current_frame_index: int, flow_values: np.ndarray, rows: np.ndarray,
+                    cols: np.ndarray) -> np.ndarray:
+        """derotate() restricted to the pixels (rows[k], cols[k]) whose flow vectors are flow_values[k]: the correction is
+        pointwise, so selecting first and derotating after gives the values the reference gets by derotating the whole field
+        and selecting (processor.py:310,343-345 need the ground-truth flow at the few hundred drone pixels only).  Host numpy in
+        the reference's operation order (detector.py:83-117); float64 out, frame 0 untouched."""
+        if current_frame_index < 1:
+            return flow_values
+        dt = self.dataset.get_delta_time(current_frame_index)
+        w, h = self.dataset.capture_size[0], self.dataset.capture_size[1]
+        omega = np.asarray(self.dataset.get_angular_difference(previous_frame_index, current_frame_index), np.float64) / dt
+        x = -(np.asarray(cols) / w - 0.5) * 2.0
+        y = -(np.asarray(rows) / h - 0.5) * 2.0
+        du = +omega[0] * x * y - omega[1] * x ** 2 - omega[1] + omega[2] * y
+        dv = -omega[2] * x + omega[0] + omega[0] * y ** 2 - omega[1] * x * y
+        du = du * (w * dt / 2)
+        dv = dv * (h * dt / 2)
+        return flow_values - np.stack([du, dv], axis=-1)
+
     @staticmethod
     def _gray_of(img: np.ndarray, who: str):
         a = np.asarray(img)

@@ -1,0 +1,61 @@
+"""The reference's flow seam -- Dataset.get_flow_uv(i) -> float32 (H, W, 2) (/root/reference/src/datasets/dataset.py:205-212,
+called at src/processor.py:287,305) -- as two small providers a dataset object can delegate to:
+
+    FloFlowProvider         what the reference does today: read `{img_path}/output/inference/run.epoch-0-flow-field/{i:06d}.flo`
+                            (FlowNet2's output directory) with utils.read_flow.
+    FarnebackFlowProvider   the same call answered by libmavflow's Farneback on the GPU from the sequence's gray frames, optionally
+                            writing each field back as a .flo file in the reference's layout so that every other consumer of
+                            those files (validator, plots) keeps working unchanged.
+
+Flow i is the field from frame i to frame i + 1.  Errors follow the reference: a missing file is an OSError, a bad tag an
+AssertionError (utils.py:217).
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, Optional
+
+import numpy as np
+
+from . import utils
+
+
+def flo_path(img_path: str, i: int) -> str:
+    """dataset.py:211"""
+    return f"{img_path}/output/inference/run.epoch-0-flow-field/{i:06d}.flo"
+
+
+class FloFlowProvider:
+    def __init__(self, img_path: str) -> None:
+        self.img_path = img_path
+
+    def get_flow_uv(self, i: int) -> np.ndarray:
+        return utils.read_flow(flo_path(self.img_path, i))
+
+
+class FarnebackFlowProvider:
+    """get_gray(i) -> u8 (H, W) frame i (BGR frames are converted on the GPU).  One context, one pair per call, exactly the call
+    shape of src/farneback.py:76-80; `cache` keeps the previous frame's upload-side conversion."""
+
+    def __init__(self, get_gray: Callable[[int], np.ndarray], width: int, height: int, img_path: Optional[str] = None,
+                 write_flo: bool = False) -> None:
+        from . import _lib
+        self.get_gray, self.img_path, self.write_flo = get_gray, img_path, write_flo
+        self.ctx = _lib.Context(width, height, 1)
+        if write_flo and not img_path:
+            raise ValueError("write_flo needs img_path")
+
+    def _gray(self, i: int) -> np.ndarray:
+        f = np.asarray(self.get_gray(i))
+        return self.ctx.bgr2gray(f)[0] if f.ndim == 3 else np.ascontiguousarray(f, np.uint8)
+
+    def get_flow_uv(self, i: int) -> np.ndarray:
+        flow = self.ctx.farneback(self._gray(i), self._gray(i + 1))[0]
+        if self.write_flo:
+            path = flo_path(self.img_path, i)
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            utils.write_flow(path, flow)
+        return flow
+
+    def release(self) -> None:
+        self.ctx.close()

@@ -1,7 +1,8 @@
 """Processor -- the detection loop of /root/reference/src/processor.py:277-396 (FoE branch) on libmavflow.
 
 run_detection() keeps the reference's shape: one frame index at a time, the same order of operations
-(:305-341), the same FrameResult fields (:353-362).  run_detection_batched() is the MI355X form of the same loop:
+(:305-341), the same FrameResult fields (:353-362); run_detection_staged() is that loop through the reference-named
+calls one at a time.  run_detection_batched() is the MI355X form of the same loop:
 frame pairs are independent once the flow no longer comes from files, so they go through the fused
 mav_process_batch entry point `batch` pairs at a time.  File / video / PNG output and the homography branch are
 outside the hot path and are not reproduced."""
@@ -113,14 +114,17 @@ class Processor:
     def is_active(self) -> bool:
         return self.frame_index < self.dataset.N - 1 and not self.is_exiting
 
-    # -- validation tail shared by both loops (processor.py:343-362) --------------------------------------------------
-    def _fill_result(self, i: int, foe_dense, derotated, gt_derotated, estimate_fixed, total_mask, sky_scores) -> FrameResult:
+    # -- validation tail shared by the loops (processor.py:343-362) ---------------------------------------------------
+    def _fill_result(self, i: int, foe_dense, estimate_fixed, total_mask, sky_scores) -> FrameResult:
         r = FrameResult()
         r.foe_dense = foe_dense
         r.foe_gt = utils.assert_type(self.dataset.get_gt_foe(i))
         segmentation = self.dataset.get_segmentation(i)[..., 0]
+        # ground-truth flow of the drone: derotated at the drone's pixels only (pointwise, same values as derotating the frame)
+        gt = utils.assert_type(self.dataset.get_gt_of(i))
+        rows, cols = np.nonzero(segmentation > 127)
         with np.errstate(all="ignore"):
-            drone_flow_avg_gt = np.average(gt_derotated[segmentation > 127], axis=0)
+            drone_flow_avg_gt = np.average(self.detector.derotate_at(i - self.frame_step_size, i, gt[rows, cols], rows, cols), axis=0)
         center = im_helpers.get_simple_bounding_box(segmentation).get_center()
         r.center_phi = np.rad2deg(np.arctan2(center[1] - r.foe_gt[1], center[0] - r.foe_gt[0]))
         r.tpr_fixed, r.fpr_fixed = im_helpers.calculate_tpr_fpr(segmentation, 255 * estimate_fixed)     # as processor.py:350-351
@@ -131,8 +135,44 @@ class Processor:
         r.time = self.dataset.get_time(i)
         return r
 
+    def _rates(self, i: int):
+        dt = self.dataset.get_delta_time(i)
+        return np.asarray(self.dataset.get_angular_difference(i - self.frame_step_size, i), np.float64) / dt, dt
+
     def run_detection(self) -> Dict[int, FrameResult]:
-        """One frame index at a time, staged calls, as the reference's loop body."""
+        """The reference's loop (processor.py:283-341): one frame index at a time, flow from the dataset's seam
+        (get_flow_uv: a .flo file or Farneback on the GPU), then derotation -> FoE -> phi -> masks in ONE device call
+        (mav_detect): the float32 field crosses PCIe once, the masks come back, nothing else moves.  Frame 0 takes the
+        reference's float32 path (detector.py:80-81).  The sample coordinates are drawn from np.random exactly where
+        get_FOE_dense draws them."""
+        W, H = self.dataset.capture_size
+        ctx = im_helpers._ctx(W, H)
+        while self.is_active():
+            i = self.frame_index
+            self.dataset.get_frame()
+            self.flow_uv = self.dataset.get_flow_uv(i)
+            if self.flow_uv is None:
+                raise ValueError("Could not load flow field.")
+            self.sky_mask = self.dataset.get_sky_segmentation(i)
+            sky = self.dataset.validate_sky_segment(self.sky_mask, utils.assert_type(self.dataset.get_depth(i)))
+            rand1 = np.zeros((2000, 2), dtype=np.uint32)                 # focus_of_expansion.py:69-71
+            rand1[..., 0] = np.random.randint(0, self.flow_uv.shape[0], 2000)
+            rand1[..., 1] = np.random.randint(0, self.flow_uv.shape[1], 2000)
+            omega, dt = self._rates(i) if i >= 1 else (np.zeros(3), 1.0)
+            out = ctx.detect(self.flow_uv, rand1, omega=omega, dt=dt, sky=self.sky_mask, frame0=[i < 1],
+                             foe_params=self.focus_of_expansion._foe_params(1000))
+            rec = out["results"][0]
+            self.estimate_fixed, self.total_mask = out["mask_fixed"][0], out["mask_dyn"][0]
+            r = self._fill_result(i, (float(rec["foe"][0]), float(rec["foe"][1])), self.estimate_fixed, self.total_mask, sky)
+            self.detection_results[i] = r
+            self.config.results[i] = r
+            self.frame_index += 1
+        return self.detection_results
+
+    def run_detection_staged(self) -> Dict[int, FrameResult]:
+        """The same loop through the reference-named calls one by one (Detector.derotate, get_FOE_dense, the masks): every call
+        ships its arrays across PCIe, as a maintainer who only swaps the imports would get.  Kept as the parity check of
+        those shims; run_detection() is the fast form."""
         while self.is_active():
             i = self.frame_index
             self.dataset.get_frame()
@@ -140,14 +180,12 @@ class Processor:
             if self.flow_uv is None:
                 raise ValueError("Could not load flow field.")
             self.flow_uv_derotated = self.detector.derotate(i - self.frame_step_size, i, self.flow_uv)
-            self.gt_flow_uv = utils.assert_type(self.dataset.get_gt_of(i))
-            self.gt_flow_uv_derotated = self.detector.derotate(i - self.frame_step_size, i, self.gt_flow_uv)
             self.sky_mask = self.dataset.get_sky_segmentation(i)
             sky = self.dataset.validate_sky_segment(self.sky_mask, utils.assert_type(self.dataset.get_depth(i)))
             foe = self.focus_of_expansion.get_FOE_dense(self.flow_uv_derotated)
             fixed, total = self.focus_of_expansion.get_masks(self.flow_uv_derotated, foe, self.sky_mask)
             self.estimate_fixed, self.total_mask = fixed, total
-            r = self._fill_result(i, foe, self.flow_uv_derotated, self.gt_flow_uv_derotated, fixed, total, sky)
+            r = self._fill_result(i, foe, fixed, total, sky)
             self.detection_results[i] = r
             self.config.results[i] = r
             self.frame_index += 1
@@ -175,11 +213,9 @@ class Processor:
                 sky = np.stack([self.dataset.get_sky_segmentation(i) for i in ids])
                 out = ctx.process_batch(prev, nxt, samples, omega=omega, dt=dts, sky=sky, frame0=[not r_ for r_ in rot])
                 for k, i in enumerate(ids):
-                    gt = utils.assert_type(self.dataset.get_gt_of(i))
-                    gt_der = self.detector.derotate(i - 1, i, gt)
                     rec = out["results"][k]
-                    r = self._fill_result(i, (float(rec["foe"][0]), float(rec["foe"][1])), None, gt_der,
-                                          out["mask_fixed"][k], out["mask_dyn"][k], (0.0, 0.0))
+                    r = self._fill_result(i, (float(rec["foe"][0]), float(rec["foe"][1])), out["mask_fixed"][k], out["mask_dyn"][k],
+                                          (0.0, 0.0))
                     r.box = utils.Rectangle.from_box(rec["box"])   # extra: the detection box (the reference never stores one)
                     self.detection_results[i] = r
                     self.config.results[i] = r

@@ -71,10 +71,20 @@ def test_screen_default_thresholds(ctx, foe):
     assert np.array_equal(mf[0], ef), int((mf[0] != ef).sum())
     assert np.array_equal(md[0], ed), int((md[0] != ed).sum())
     assert tuple(box[0]) == tuple(box_x[0]) == fo.simple_bounding_box(ef)
-    # float64 flow through the host entry point
-    ef, ed = oracle_masks(flow, foe, sky)
+    # float64 flow through the host entry point.  Here the planted offsets survive exactly (delta = 0 puts a pixel ON its
+    # threshold), so the exact path's own verdict at such a pixel hangs on the last bit of arccos (device library vs numpy's):
+    # the screen is held to the device's exact path, bit for bit, and that path to the oracle outside a 4-ulp band of phi.
+    with np.errstate(all="ignore"):
+        phi_o, mag_o = fo.get_phi(flow, foe), fo.get_magnitude(flow)
+        ef, ed = fo.threshold_masks(phi_o, mag_o, sky)
+        band = 4 * np.spacing(180.0)
+        near_f = np.abs(phi_o - 15.0) <= band
+        near_d = np.abs(phi_o - (0.25 + (0.5 + 8 / mag_o))) <= band
     _, mf, md, _ = ctx.phi_mask(flow, foe, sky=sky, want_phi=False)
-    assert np.array_equal(mf[0], ef) and np.array_equal(md[0], ed)
+    _, mf_x, md_x, _ = ctx.phi_mask(flow, foe, sky=sky, want_phi=True)
+    assert np.array_equal(mf[0], mf_x[0]) and np.array_equal(md[0], md_x[0])
+    assert not ((mf_x[0] != ef) & ~near_f).any() and not ((md_x[0] != ed) & ~near_d).any()
+    assert (near_f | near_d).sum() > 100                               # the knife-edge pixels are really there
     # the planted field really exercises both outcomes of both masks
     assert 0.05 < ef.mean() < 0.95 and 0.05 < ed.mean() < 0.95
 

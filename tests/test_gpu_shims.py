@@ -125,10 +125,15 @@ def test_processor_loops_agree_with_the_oracle(mav):
         np.random.seed(11)
         return Processor(cfg), ds
     p1, ds1 = make()
-    res = p1.run_detection()
+    res = p1.run_detection()                   # flow seam -> one mav_detect call per frame
     p2, ds2 = make()
-    res_b = p2.run_detection_batched(batch=2)
-    assert sorted(res) == sorted(res_b) == [0, 1, 2]
+    res_b = p2.run_detection_batched(batch=2)  # frames -> mav_process_batch, two pairs per call
+    p3, ds3 = make()
+    res_s = p3.run_detection_staged()          # the reference-named calls one by one
+    assert sorted(res) == sorted(res_b) == sorted(res_s) == [0, 1, 2]
+    for i in res:                              # frame 0 (float32 path) and the later frames agree across all three loops
+        assert vars(res[i]) == vars(res_s[i]), i
+        assert np.array_equal(p1.estimate_fixed, p3.estimate_fixed) and np.array_equal(p1.total_mask, p3.total_mask)
     # the oracle, fed the same flow and the same random draws
     np.random.seed(11)
     make()                                     # constructors consume their draws again
@@ -146,3 +151,56 @@ def test_processor_loops_agree_with_the_oracle(mav):
         assert res[i].drone_size_pixels == 24 * 24 and res[i].time == i * ds1.dt
         assert tuple(int(v) for v in (res_b[i].box.topleft + res_b[i].box.size)) == \
             (ref["box"][0], ref["box"][1], ref["box"][2] - ref["box"][0], ref["box"][3] - ref["box"][1])
+
+
+def test_farneback_flow_provider_fills_the_reference_flow_seam(mav, tmp_path, fb_oracle):
+    """Dataset.get_flow_uv (/root/reference/src/datasets/dataset.py:205-212) answered by Farneback on the GPU; the .flo files
+    it leaves behind are readable through the reference's own layout."""
+    from mavflow.flow_provider import FarnebackFlowProvider, FloFlowProvider
+    W, H = 320, 240
+    frames = [synth.make_pair(W, H, 9)[0], synth.make_pair(W, H, 9)[1], synth.make_pair(W, H, 10)[1]]
+    img = str(tmp_path / "seq" / "images")
+    prov = FarnebackFlowProvider(lambda i: frames[i], W, H, img_path=img, write_flo=True)
+    f0 = prov.get_flow_uv(0)
+    f1 = prov.get_flow_uv(1)
+    prov.release()
+    assert f0.dtype == np.float32 and f0.shape == (H, W, 2)
+    ref = fb_oracle.calc(frames[0], frames[1])
+    e = np.hypot(f0[..., 0] - ref[..., 0], f0[..., 1] - ref[..., 1])
+    assert e.mean() <= 1e-2 and np.percentile(e, 99.9) <= 1e-1
+    files = FloFlowProvider(img)
+    assert np.array_equal(files.get_flow_uv(0), f0) and np.array_equal(files.get_flow_uv(1), f1)
+    # BGR frames are converted on the device (cv2.cvtColor at farneback.py:74): a gray replica gives the same flow
+    prov = FarnebackFlowProvider(lambda i: np.repeat(frames[i][..., None], 3, axis=2), W, H)
+    assert np.array_equal(prov.get_flow_uv(0), f0)
+    prov.release()
+
+
+def test_pyramid_generator_yields_every_level(mav):
+    """im_helpers.pyramid (/root/reference/src/im_helpers.py:12-35) + sliding_window, iterated as Detector.analyze_pyramid does
+    (detector.py:296-310), must reproduce analyze_pyramid's own answer -- same levels, same images."""
+    from mavflow import im_helpers
+    from mavflow.detector import Detector
+    from oracle import pyramid_oracle as po
+    W, H = 400, 300
+    rng = np.random.default_rng(3)
+    gray = (rng.integers(0, 30, (H, W)) * (rng.random((H, W)) > 0.9)).astype(np.uint8)
+    gray[200:260, 120:200] = 90                                    # a blob that wins at a coarser level
+    rgb = np.repeat(gray[..., None], 3, axis=2)
+    levels = list(im_helpers.pyramid(rgb, scale=1.5))
+    dims = im_helpers._ctx(W, H).pyramid_dims(1.5)
+    assert [l.shape[:2] for l in levels] == [(h, w) for (w, h) in dims] and len(levels) >= 4
+    exp = list(po.pyramid(gray, 1.5))
+    for l, lv in enumerate(levels[1:], 1):                         # levels >= 1 equal the oracle's INTER_AREA cascade
+        assert np.array_equal(lv[..., 0], exp[l]), l
+    best = (0, None, None, None)
+    for lv in levels:
+        for (x, y, window) in im_helpers.sliding_window(lv, stepSize=16, windowSize=(64, 64)):
+            if window.shape[0] != 64 or window.shape[1] != 64:
+                continue
+            s = int(np.sum(window))
+            if best[0] < s:
+                best = (s, x, y, window)
+    d = Detector(type("DS", (), {"capture_size": (W, H)})())
+    score, rect, window, _ = d.analyze_pyramid(rgb)
+    assert (score, rect.topleft) == (best[0], (best[1], best[2])) and np.array_equal(window, best[3])

@@ -84,3 +84,62 @@ def test_gray_and_int_helpers():
     a = np.array([[0.0, 90.0, 180.0]])
     assert im_helpers.to_int(a, np.uint8, True, 180.0).tolist() == [[0, 128, 255]]
     assert im_helpers.to_rgb(a, 180.0).shape == (1, 3, 3)
+
+
+@pytest.fixture(scope="module")
+def io_golden():
+    import os
+    from conftest import GOLDEN
+    return np.load(os.path.join(GOLDEN, "frame0_io.npz"), allow_pickle=False)
+
+
+def test_flo_bytes_and_arrays_match_the_reference(tmp_path, io_golden):
+    """utils.write_flow / read_flow against the bytes and arrays the reference's own functions produced
+    (/root/reference/src/utils.py:204-257; tools/gen_golden.py)."""
+    flo = io_golden["flo_in"]
+    p = tmp_path / "a.flo"
+    utils.write_flow(str(p), flo)
+    assert p.read_bytes() == io_golden["flo_bytes"].tobytes()
+    utils.write_flow(str(p), flo[..., 0].astype(np.float64), flo[..., 1].astype(np.float64))        # separate u, v planes
+    assert p.read_bytes() == io_golden["flo_bytes_uv"].tobytes()
+    p.write_bytes(io_golden["flo_bytes"].tobytes())                    # a file the reference wrote
+    back = utils.read_flow(str(p))
+    assert back.dtype == np.dtype(str(io_golden["flo_read_dtype"])) and back.tobytes() == io_golden["flo_read"].tobytes()
+    assert back.shape == io_golden["flo_read"].shape == (37, 53, 2)
+
+
+def test_flo_flow_provider_reads_the_reference_layout(tmp_path, io_golden):
+    """Dataset.get_flow_uv (/root/reference/src/datasets/dataset.py:205-212): same path layout, same array, same errors."""
+    from mavflow.flow_provider import FloFlowProvider, flo_path
+    img = tmp_path / "seq" / "images"
+    path = flo_path(str(img), 7)
+    assert path.endswith("/output/inference/run.epoch-0-flow-field/000007.flo")
+    import os
+    os.makedirs(os.path.dirname(path))
+    open(path, "wb").write(io_golden["flo_bytes"].tobytes())
+    prov = FloFlowProvider(str(img))
+    assert prov.get_flow_uv(7).tobytes() == io_golden["flo_read"].tobytes()
+    with pytest.raises(OSError):
+        prov.get_flow_uv(8)
+    open(flo_path(str(img), 9), "wb").write(b"\0" * 64)
+    with pytest.raises(AssertionError):
+        prov.get_flow_uv(9)
+
+
+def test_frame_result_json_matches_the_reference_text(io_golden):
+    """processor.py:83-84 writes json.dumps(utils.get_json(result), indent=4, sort_keys=True) per frame: same text, including the
+    numpy integers and float32 values that get_json turns into strings and the NaN a 0/0 rate leaves behind."""
+    import json
+    r = FrameResult()
+    r.foe_dense = (np.float64(297.87096720308574), np.float64(222.21492686396977))
+    r.foe_gt = (352.0, 216.0)
+    r.center_phi = np.float64(-143.13010235415598)
+    r.tpr_fixed, r.fpr_fixed = np.float64(0.75), np.float64(0.001953125)
+    r.tpr, r.fpr = np.float64(1.0) / np.float64(3.0), np.float64("nan")
+    r.sky_tpr, r.sky_fpr = (0.0, 0.0)
+    r.drone_flow_pixels = (np.float32(6.0), np.float32(-3.0))
+    r.drone_size_pixels = np.sum(np.ones((24, 24)) > 0)
+    r.time = 4 * (1 / 30.0)
+    text = json.dumps(utils.get_json(r), indent=4, sort_keys=True)
+    assert text == str(io_golden["json_text"])
+    assert json.dumps(utils.get_json(vars(r)), indent=4, sort_keys=True) == text      # the dict form gives the same document
