@@ -253,10 +253,14 @@ static __device__ __forceinline__ void wave_box_commit(int x0, int y0, int x1, i
 // Screening constants for the single-precision fast path (host-computed, see phi_screen()).
 struct PhiScreen {
     int enabled;         // 0: every pixel takes the exact double path
+    int fixed_tan;       // fixed_deg in (0, 80): the fixed threshold is screened in the tangent form
     float cos_fixed;     // cos(fixed_deg)
+    float tan_fixed;     // tan(fixed_deg)
     float fmm2, dmm2;    // fixed_min_mag^2, dyn_min_mag^2
     float dyn_ab, dyn_c; // dyn_a + dyn_b, dyn_c
 };
+#define MAV_SCREEN_TAN_MAX_DEG 17.0f     // the degree-9 series of tan below is good to 5e-8 relative up to 0.2967 rad
+#define MAV_SCREEN_TAN_MARGIN 4e-6f      // decision margin, in units of |flow| * |p - FoE| * (1 + tan T); error bound 1.2e-6
 
 // Exact phi of one pixel (degrees), numpy order of operations (focus_of_expansion.py:163-177).
 static __device__ __forceinline__ double phi_exact(double u, double v, double d2x, double d2y, double* fm_out)
@@ -280,24 +284,46 @@ static __device__ __forceinline__ void phi_pixel(double u, double v, int x, int 
     const double d2x = (double)x - foex, d2y = (double)y - foey;
     *have_ph = false;
     if (scr.enabled) {
-        // Single-precision screen.  phi > T  <=>  arg < cos(T)  (arccos is monotone), and every f32 quantity below is within
-        // 1e-6 (absolute, in arg units) / 1e-6 (relative, magnitudes) of its double counterpart, so a decision taken outside
-        // the guard bands is the decision the exact path would take.  Pixels inside a band (a ~1e-4 fraction) fall through.
+        // Single-precision screen.  For a threshold T below 90 degrees
+        //     phi > T   <=>   dot <= 0  or  |cross| > tan(T) * dot        (dot = f . d, cross = f x d, d = p - FoE),
+        // and this form is well conditioned exactly where the thresholds live (a few degrees): in float32 dot and |cross| are
+        // each within 4.2e-7 S of their exact values (S = |f| |d|), tan(T) within 6.5e-7 relative, so  r = |cross| - tan(T) dot
+        // is within 1.2e-6 S (1 + tan T) of its exact value and its sign is the exact path's verdict whenever |r| exceeds the
+        // 4e-6 margin: an angular band of ~2e-4 degrees, ~1e-5 of the pixels.  (The arccos-argument form used before, arg < cos T
+        // with a 1e-4 band, is ill conditioned at small T -- d arg = sin T dT -- and sent every pixel within ~0.15 degrees of a
+        // 2-degree threshold down the double path: most waves of a real flow field.)  The cosine form remains for dynamic
+        // thresholds above 17 degrees (|flow| < 0.5, reachable only with non-default gates).  Gates: 1e-5 relative around both.
         const float uf = (float)u, vf = (float)v, dxf = (float)d2x, dyf = (float)d2y;
         const float m2 = uf * uf + vf * vf, dd = dxf * dxf + dyf * dyf;
         const float prod2 = m2 * dd;
-        const float arg = (uf * dxf + vf * dyf) * rsqrtf(prod2);
+        const float dot = uf * dxf + vf * dyf;
+        const float crs = fabsf(uf * dyf - vf * dxf);
+        const float S = sqrtf(prod2);
         bool sure = prod2 > 1e-8f && prod2 < 1e30f;       // norm floor (1e-6) and inf/NaN stay on the exact path
         const bool gate_f = m2 > scr.fmm2, gate_d = m2 > scr.dmm2;
         sure = sure && fabsf(m2 - scr.fmm2) > 1e-5f * scr.fmm2 && fabsf(m2 - scr.dmm2) > 1e-5f * scr.dmm2;
         bool f = false, d = false;
         if (gate_f && notsky) {
-            sure = sure && fabsf(arg - scr.cos_fixed) > 2e-5f;
-            f = arg < scr.cos_fixed;
+            if (scr.fixed_tan) {
+                const float r = crs - scr.tan_fixed * dot;
+                sure = sure && fabsf(r) > MAV_SCREEN_TAN_MARGIN * S * (1.f + scr.tan_fixed);
+                f = r > 0.f;
+            } else {
+                const float arg = dot * rsqrtf(prod2);
+                sure = sure && fabsf(arg - scr.cos_fixed) > 2e-5f;
+                f = arg < scr.cos_fixed;
+            }
         }
         if (gate_d && notsky) {
-            const float T = scr.dyn_ab + scr.dyn_c * rsqrtf(m2);  // degrees
-            if (T < 179.f) {
+            const float T = scr.dyn_ab + scr.dyn_c * rsqrtf(m2);  // degrees, >= 0
+            if (T < MAV_SCREEN_TAN_MAX_DEG) {
+                const float x = T * 0.017453292519943295f, x2 = x * x;
+                const float tT = x * (1.f + x2 * (0.33333333333f + x2 * (0.13333333333f + x2 * (0.05396825397f + x2 * 0.02186948854f))));
+                const float r = crs - tT * dot;
+                sure = sure && fabsf(r) > MAV_SCREEN_TAN_MARGIN * S * (1.f + tT);
+                d = r > 0.f;
+            } else if (T < 179.f) {
+                const float arg = dot * rsqrtf(prod2);
                 const float cT = __cosf(T * 0.017453292519943295f);
                 sure = sure && fabsf(arg - cT) > 1e-4f;
                 d = arg < cT;
@@ -445,6 +471,8 @@ static PhiScreen phi_screen(const mav_thr_params& t, const double* phi, const un
                     t.fixed_min_mag < 1e6 && t.dyn_min_mag < 1e6 && t.dyn_c < 1e6 && t.dyn_a + t.dyn_b < 1e3;
     { const char* e = getenv("MAVFLOW_NO_SCREEN"); s.enabled = ok && !(e && atoi(e) != 0); }
     s.cos_fixed = (float)cos(t.fixed_deg * 3.141592653589793238462643383279502884 / 180.0);
+    s.fixed_tan = t.fixed_deg > 0.0 && t.fixed_deg < 80.0;
+    s.tan_fixed = s.fixed_tan ? (float)tan(t.fixed_deg * 3.141592653589793238462643383279502884 / 180.0) : 0.f;
     s.fmm2 = (float)(t.fixed_min_mag * t.fixed_min_mag);
     s.dmm2 = (float)(t.dyn_min_mag * t.dyn_min_mag);
     s.dyn_ab = (float)(t.dyn_a + t.dyn_b);

@@ -13,6 +13,51 @@
 
 static __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// ------------------------------------------------------------------------------------------------------------
+// Workgroup -> tile mapping shared by the tiled kernels (64 x 16 pixel tiles over G images).
+// Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one, each XCD has its own 4 MB L2), so workgroup b
+// takes tile (b & 7) * per + (b >> 3): every XCD walks ONE contiguous run of tiles and the halo rows / gather rows that
+// vertically adjacent tiles share are re-read from that XCD's L2 instead of HBM (a plain 2-D grid puts neighbours on
+// different XCDs: measured 3.9x read over-fetch in the expansion kernel).  Inside an image the run goes through column
+// STRIPS of strip_w tiles, row by row inside a strip: the tiles resident on an XCD at one time (~160) then span several
+// tile rows of the strip, so a tile's upper neighbour is still in L2 when it is needed -- on a 3840-wide layer one tile row
+// is 60 tiles and without strips the reuse distance exceeds the L2.  Speed only: every tile is computed exactly once and
+// nothing depends on the order.  Grid = n_tiles rounded up to a multiple of 8.
+// ------------------------------------------------------------------------------------------------------------
+struct TileMap { int tiles_x, tiles_y, per_img, n_tiles, strip_w; };
+static __device__ __forceinline__ bool tile_of_block(const TileMap& tm, int* s, int* tx, int* ty)
+{
+    const int per = ((int)gridDim.x + 7) >> 3;
+    const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (tile >= tm.n_tiles) return false;
+    const int img = tile / tm.per_img;
+    int tr = tile - img * tm.per_img;
+    const int strip_tiles = tm.strip_w * tm.tiles_y;          // every strip but the last is strip_w tiles wide
+    const int st = tr / strip_tiles;
+    tr -= st * strip_tiles;
+    const int x_base = st * tm.strip_w;
+    const int sw = min(tm.strip_w, tm.tiles_x - x_base);
+    const int row = tr / sw;
+    *s = img; *ty = row; *tx = x_base + tr - row * sw;
+    return true;
+}
+static int g_strip_override = -1;                                // MAVFLOW_STRIP: tuning experiments only
+static TileMap make_tile_map(int w, int h, int G, int tile_w, int tile_h)
+{
+    TileMap tm;
+    tm.tiles_x = (w + tile_w - 1) / tile_w;
+    tm.tiles_y = (h + tile_h - 1) / tile_h;
+    tm.per_img = tm.tiles_x * tm.tiles_y;
+    tm.n_tiles = tm.per_img * G;
+    if (g_strip_override < 0) { const char* e = getenv("MAVFLOW_STRIP"); g_strip_override = e ? atoi(e) : 0; }
+    int sw = tm.tiles_x;
+    if (g_strip_override > 0) sw = g_strip_override < tm.tiles_x ? g_strip_override : tm.tiles_x;
+    else if (tm.tiles_x > 40) { const int ns = (tm.tiles_x + 29) / 30; sw = (tm.tiles_x + ns - 1) / ns; }
+    tm.strip_w = sw;
+    return tm;
+}
+static inline unsigned tile_grid(const TileMap& tm) { return (unsigned)(((tm.n_tiles + 7) / 8) * 8); }
+
 #ifdef MAV_STAMPS   // diagnostic build only (tools/phase_stamps.py): per-phase wave cycles of the sweep kernel, never in the product .so
 #define MAV_STAMP_WAVES (1 << 17)
 __device__ unsigned long long g_phase_cycles[MAV_STAMP_WAVES * 8];   // one row per wave slot of a launch: plain += (launches are serial)
@@ -264,9 +309,11 @@ void launch_blur_resize(hipStream_t st, const uint8_t* img, size_t img_stride, i
 #define PX 64
 #define PY 16
 template <int N_T>
-__global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ I, size_t I_stride, int w, int h, PolyCoef pc,
+__global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ I, size_t I_stride, int w, int h, PolyCoef pc, TileMap tm,
                                                  float* __restrict__ R, size_t R_stride)
 {
+    int img_s, tile_x, tile_y;
+    if (!tile_of_block(tm, &img_s, &tile_x, &tile_y)) return;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n = N_T > 0 ? N_T : pc.n;
     const int EX = PX + 2 * n, EY = PY + 2 * n;
@@ -275,8 +322,8 @@ __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ I, si
     float* v1 = v0 + PY * EX;
     float* v2 = v1 + PY * EX;
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * PX, y0 = blockIdx.y * PY;
-    const float* src = I + (size_t)blockIdx.z * I_stride;
+    const int x0 = tile_x * PX, y0 = tile_y * PY;
+    const float* src = I + (size_t)img_s * I_stride;
 
     if constexpr (N_T > 0) {
         // all of a thread's loads are issued before the first one is consumed (a load -> LDS-store loop would serialise
@@ -319,7 +366,7 @@ __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ I, si
     }
     __syncthreads();
     const size_t npx = (size_t)w * h;
-    float* dst = R + (size_t)blockIdx.z * R_stride;
+    float* dst = R + (size_t)img_s * R_stride;
     for (int i = tid; i < PY * PX; i += 256) {
         const int ly = i >> 6, lx = i & 63;
         const int gx = x0 + lx, gy = y0 + ly;
@@ -354,15 +401,16 @@ void launch_polyexp(hipStream_t st, const float* I, size_t I_stride, int G, int 
 {
     const int n = pc.n;
     const size_t lds = sizeof(float) * ((size_t)(PX + 2 * n) * (PY + 2 * n) + 3 * (size_t)PY * (PX + 2 * n));
-    dim3 grid((w + PX - 1) / PX, (h + PY - 1) / PY, G);
+    const TileMap tm = make_tile_map(w, h, G, PX, PY);
+    const dim3 grid(tile_grid(tm));
     if (n == 8)
-        hipLaunchKernelGGL(k_polyexp<8>, grid, dim3(256), lds, st, I, I_stride, w, h, pc, R, R_stride);
+        hipLaunchKernelGGL(k_polyexp<8>, grid, dim3(256), lds, st, I, I_stride, w, h, pc, tm, R, R_stride);
     else if (n == 7)
-        hipLaunchKernelGGL(k_polyexp<7>, grid, dim3(256), lds, st, I, I_stride, w, h, pc, R, R_stride);
+        hipLaunchKernelGGL(k_polyexp<7>, grid, dim3(256), lds, st, I, I_stride, w, h, pc, tm, R, R_stride);
     else if (n == 5)
-        hipLaunchKernelGGL(k_polyexp<5>, grid, dim3(256), lds, st, I, I_stride, w, h, pc, R, R_stride);
+        hipLaunchKernelGGL(k_polyexp<5>, grid, dim3(256), lds, st, I, I_stride, w, h, pc, tm, R, R_stride);
     else
-        hipLaunchKernelGGL(k_polyexp<0>, grid, dim3(256), lds, st, I, I_stride, w, h, pc, R, R_stride);
+        hipLaunchKernelGGL(k_polyexp<0>, grid, dim3(256), lds, st, I, I_stride, w, h, pc, tm, R, R_stride);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -461,46 +509,85 @@ static __device__ __forceinline__ float2 upsample_flow(const float* __restrict__
 
 // Initial M of a layer.  flow = 0 (top layer), resize(prevFlow)*mul evaluated inline (lower layers), or an
 // explicit flow field (stage hook).  The upsampled flow is never written: the first blur sweep overwrites it.
+// 64 x 16 pixel tile per workgroup in the XCD-aware order of tile_of_block(): lane = pixel column, wave v owns tile rows
+// 4v .. 4v+3, so a wave's R0 loads, R1 gathers and M stores are row-contiguous, the 2x2 gather rows of vertically adjacent
+// pixels are re-used from L1 / the XCD's L2 (a 64 x 4 block per workgroup on a 2-D grid fetched them 1.5x), all 20 R0 loads of
+// a thread are requested up front and the gathers of two pixels are in flight together (gather_issue / update_finish below).
+struct GatherPx;
+static __device__ __forceinline__ void gather_issue(const float* __restrict__ R1p, size_t npx, int w, int h, int x, int y, float dx,
+                                                    float dy, GatherPx& g);
+static __device__ __forceinline__ void update_finish(const float q[5], const GatherPx& g, int w, int h, int x, int y, float dx,
+                                                     float dy, float out[5]);
+struct GatherPx {
+    float p00[5], p01[5], p10[5], p11[5];
+    float fx, fy;
+    bool inside;
+};
 template <int MODE>  // 0 zero, 1 upsample, 2 explicit
 __global__ __launch_bounds__(256) void k_update_matrices(const float* __restrict__ R0, const float* __restrict__ R1,
                                                          size_t R_stride, const float* __restrict__ fsrc, size_t f_stride,
                                                          int pw, int ph, float mul, double scale_x, double scale_y, int w,
-                                                         int h, float* __restrict__ M, size_t M_stride)
+                                                         int h, TileMap tm, float* __restrict__ M, size_t M_stride)
 {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
-    const int s = blockIdx.z;
-    float dx = 0.f, dy = 0.f;
-    if (MODE == 1) {
-        const float2 f = upsample_flow(fsrc + (size_t)s * f_stride, pw, ph, mul, scale_x, scale_y, x, y);
-        dx = f.x; dy = f.y;
-    } else if (MODE == 2) {
-        const float2 f = *(const float2*)(fsrc + (size_t)s * f_stride + ((size_t)y * w + x) * 2);
-        dx = f.x; dy = f.y;
+    int s, tx, ty;
+    if (!tile_of_block(tm, &s, &tx, &ty)) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x = tx * 64 + lane, xc = min(x, w - 1);
+    const int yb = ty * 16 + wv * 4;
+    const size_t npx = (size_t)w * h;
+    const float* R0p = R0 + (size_t)s * R_stride;
+    const float* R1p = R1 + (size_t)s * R_stride;
+    float* Mp = M + (size_t)s * M_stride;
+    float q[4][5];
+    float2 f[4];
+    int ys[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        ys[j] = min(yb + j, h - 1);
+        const size_t idx = (size_t)ys[j] * w + xc;
+#pragma unroll
+        for (int c = 0; c < 5; c++) q[j][c] = R0p[c * npx + idx];
+        if (MODE == 1) f[j] = upsample_flow(fsrc + (size_t)s * f_stride, pw, ph, mul, scale_x, scale_y, xc, ys[j]);
+        else if (MODE == 2) f[j] = *(const float2*)(fsrc + (size_t)s * f_stride + idx * 2);
+        else f[j] = make_float2(0.f, 0.f);
     }
-    update_px(R0 + (size_t)s * R_stride, R1 + (size_t)s * R_stride, (size_t)w * h, w, h, x, y, dx, dy,
-              M + (size_t)s * M_stride);
+#pragma unroll
+    for (int jb = 0; jb < 4; jb += 2) {
+        GatherPx g[2];
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) gather_issue(R1p, npx, w, h, xc, ys[jb + jj], f[jb + jj].x, f[jb + jj].y, g[jj]);
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) {
+            float o[5];
+            update_finish(q[jb + jj], g[jj], w, h, xc, ys[jb + jj], f[jb + jj].x, f[jb + jj].y, o);
+            if (x < w && yb + jb + jj < h) {
+                const size_t idx = (size_t)ys[jb + jj] * w + xc;
+#pragma unroll
+                for (int c = 0; c < 5; c++) Mp[c * npx + idx] = o[c];
+            }
+        }
+    }
 }
 
 void launch_update_matrices(hipStream_t st, const float* R0, const float* R1, size_t R_stride, const float* flow_prev,
                             size_t fp_stride, int pw, int ph, float mul, int G, int w, int h, float* M, size_t M_stride)
 {
-    dim3 grid((w + 63) / 64, (h + 3) / 4, G);
+    const TileMap tm = make_tile_map(w, h, G, 64, 16);
+    const dim3 grid(tile_grid(tm));
     if (flow_prev)
         hipLaunchKernelGGL(k_update_matrices<1>, grid, dim3(256), 0, st, R0, R1, R_stride, flow_prev, fp_stride, pw, ph, mul,
-                           (double)pw / w, (double)ph / h, w, h, M, M_stride);
+                           (double)pw / w, (double)ph / h, w, h, tm, M, M_stride);
     else
         hipLaunchKernelGGL(k_update_matrices<0>, grid, dim3(256), 0, st, R0, R1, R_stride, (const float*)nullptr, (size_t)0,
-                           0, 0, 0.f, 0.0, 0.0, w, h, M, M_stride);
+                           0, 0, 0.f, 0.0, 0.0, w, h, tm, M, M_stride);
 }
 
 void launch_update_matrices_flow(hipStream_t st, const float* R0, const float* R1, size_t R_stride, const float* flow,
                                  size_t f_stride, int G, int w, int h, float* M, size_t M_stride)
 {
-    dim3 grid((w + 63) / 64, (h + 3) / 4, G);
-    hipLaunchKernelGGL(k_update_matrices<2>, grid, dim3(256), 0, st, R0, R1, R_stride, flow, f_stride, 0, 0, 0.f, 0.0, 0.0,
-                       w, h, M, M_stride);
+    const TileMap tm = make_tile_map(w, h, G, 64, 16);
+    hipLaunchKernelGGL(k_update_matrices<2>, dim3(tile_grid(tm)), dim3(256), 0, st, R0, R1, R_stride, flow, f_stride, 0, 0, 0.f, 0.0,
+                       0.0, w, h, tm, M, M_stride);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -625,11 +712,6 @@ __global__ __launch_bounds__(256) void k_blur_iter_generic(const float* __restri
 #define FT_X 64
 #define FT_Y 16
 
-struct GatherPx {
-    float p00[5], p01[5], p10[5], p11[5];
-    float fx, fy;
-    bool inside;
-};
 // request the 2x2 neighbourhood of the 5 R1 planes around (x + dx, y + dy); out-of-image taps read a clamped address
 static __device__ __forceinline__ void gather_issue(const float* __restrict__ R1p, size_t npx, int w, int h, int x, int y, float dx,
                                                     float dy, GatherPx& g)
@@ -689,7 +771,7 @@ template <int M_T, bool AL = true>
 __global__ __launch_bounds__(256) void k_blur_iter_fast(const float* __restrict__ M_in, float* __restrict__ M_out,
                                                         size_t M_stride, const float* __restrict__ R0,
                                                         const float* __restrict__ R1, size_t R_stride, int w, int h,
-                                                        int tiles_x, int tiles_per_img, int n_tiles, float scale,
+                                                        TileMap tm, float scale,
                                                         int do_update, int store_flow, float* __restrict__ flow, size_t f_stride)
 {
     constexpr int EXT_X = FT_X + 2 * M_T;              // 76
@@ -701,14 +783,8 @@ __global__ __launch_bounds__(256) void k_blur_iter_fast(const float* __restrict_
     __shared__ __attribute__((aligned(16))) float vs[5 * PLANE];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
-    // XCD-aware tile order: workgroups b, b+8, b+16, ... (one XCD) take consecutive tiles of one band
-    const int nb = gridDim.x;
-    const int per = (nb + 7) >> 3;
-    const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-    if (tile >= n_tiles) return;
-    const int s = tile / tiles_per_img;
-    const int tr = tile - s * tiles_per_img;
-    const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+    int s, tx, ty;                                       // XCD-aware tile order, see tile_of_block()
+    if (!tile_of_block(tm, &s, &tx, &ty)) return;
     const int x0 = tx * FT_X, y0 = ty * FT_Y;
     const size_t npx = (size_t)w * h;
     const float* Min = M_in + (size_t)s * M_stride;
@@ -879,9 +955,8 @@ __global__ __launch_bounds__(256) void k_blur_iter_fast(const float* __restrict_
 template <int M_T, int MODE>  // MODE 0: zero flow in, 1: upsampled coarse flow, 2: explicit flow (h, w, 2)
 __global__ __launch_bounds__(256) void k_sweep_rc(const float* __restrict__ fin, size_t fin_stride, int pw, int ph, float mul,
                                                   double scale_x, double scale_y, const float* __restrict__ R0,
-                                                  const float* __restrict__ R1, size_t R_stride, int w, int h, int tiles_x,
-                                                  int tiles_per_img, int n_tiles, float scale, float* __restrict__ fout,
-                                                  size_t fout_stride)
+                                                  const float* __restrict__ R1, size_t R_stride, int w, int h, TileMap tm,
+                                                  float scale, float* __restrict__ fout, size_t fout_stride)
 {
     constexpr int EXT_X = FT_X + 2 * M_T;              // 76
     constexpr int EXT_Y = FT_Y + 2 * M_T;              // 28
@@ -894,13 +969,8 @@ __global__ __launch_bounds__(256) void k_sweep_rc(const float* __restrict__ fin,
     __shared__ __attribute__((aligned(16))) float ms[5 * PLANE];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
-    const int nb = gridDim.x;
-    const int per = (nb + 7) >> 3;
-    const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-    if (tile >= n_tiles) return;
-    const int s = tile / tiles_per_img;
-    const int tr = tile - s * tiles_per_img;
-    const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+    int s, tx, ty;
+    if (!tile_of_block(tm, &s, &tx, &ty)) return;
     const int x0 = tx * FT_X, y0 = ty * FT_Y;
     const size_t npx = (size_t)w * h;
     const float* R0p = R0 + (size_t)s * R_stride;
@@ -1025,19 +1095,15 @@ void launch_blur_iter(hipStream_t st, const float* M_in, float* M_out, size_t M_
     const bool vec_ok = (w % 4 == 0) && (M_stride % 4 == 0) && (R_stride % 4 == 0) && (f_stride % 4 == 0) && aligned16(M_in) &&
                         aligned16(M_out) && aligned16(R0) && aligned16(R1) && aligned16(flow);
     if (m == 6 && vec_ok) {
-        const int tiles_x = (w + FT_X - 1) / FT_X, tiles_y = (h + FT_Y - 1) / FT_Y;
-        const int per_img = tiles_x * tiles_y, n_tiles = per_img * G;
-        const int nb = ((n_tiles + 7) / 8) * 8;        // the XCD-aware renumbering needs a multiple of 8 workgroups
-        hipLaunchKernelGGL(k_blur_iter_fast<6>, dim3(nb), dim3(256), 0, st, M_in, M_out, M_stride, R0, R1, R_stride, w, h,
-                           tiles_x, per_img, n_tiles, scale, do_update, store_flow, flow, f_stride);
+        const TileMap tm = make_tile_map(w, h, G, FT_X, FT_Y);
+        hipLaunchKernelGGL(k_blur_iter_fast<6>, dim3(tile_grid(tm)), dim3(256), 0, st, M_in, M_out, M_stride, R0, R1, R_stride, w, h,
+                           tm, scale, do_update, store_flow, flow, f_stride);
         return;
     }
     if (m == 6 && f_stride % 2 == 0 && ((uintptr_t)flow & 7) == 0) {    // any width / alignment: relaxed form of the same kernel
-        const int tiles_x = (w + FT_X - 1) / FT_X, tiles_y = (h + FT_Y - 1) / FT_Y;
-        const int per_img = tiles_x * tiles_y, n_tiles = per_img * G;
-        const int nb = ((n_tiles + 7) / 8) * 8;
-        hipLaunchKernelGGL((k_blur_iter_fast<6, false>), dim3(nb), dim3(256), 0, st, M_in, M_out, M_stride, R0, R1, R_stride, w, h,
-                           tiles_x, per_img, n_tiles, scale, do_update, store_flow, flow, f_stride);
+        const TileMap tm = make_tile_map(w, h, G, FT_X, FT_Y);
+        hipLaunchKernelGGL((k_blur_iter_fast<6, false>), dim3(tile_grid(tm)), dim3(256), 0, st, M_in, M_out, M_stride, R0, R1, R_stride,
+                           w, h, tm, scale, do_update, store_flow, flow, f_stride);
         return;
     }
     iter_geometry(m, &ext, &pitch, &plane);
@@ -1069,18 +1135,17 @@ bool launch_sweep_rc(hipStream_t st, int mode, const float* fin, size_t fin_stri
                     aligned16(R1) && aligned16(fout) && (mode == 0 || (fin && ((uintptr_t)fin & 7) == 0 && fin_stride % 2 == 0));
     if (!ok) return false;
     const float scale = (float)(1.0 / ((double)winsize * winsize));
-    const int tiles_x = (w + FT_X - 1) / FT_X, tiles_y = (h + FT_Y - 1) / FT_Y;
-    const int per_img = tiles_x * tiles_y, n_tiles = per_img * G;
-    const int nb = ((n_tiles + 7) / 8) * 8;
+    const TileMap tm = make_tile_map(w, h, G, FT_X, FT_Y);
+    const dim3 nb(tile_grid(tm));
     const double sx = pw > 0 ? (double)pw / w : 0.0, sy = ph > 0 ? (double)ph / h : 0.0;
     if (mode == 0)
-        hipLaunchKernelGGL((k_sweep_rc<6, 0>), dim3(nb), dim3(256), 0, st, fin, fin_stride, pw, ph, mul, sx, sy, R0, R1, R_stride, w,
-                           h, tiles_x, per_img, n_tiles, scale, fout, fout_stride);
+        hipLaunchKernelGGL((k_sweep_rc<6, 0>), nb, dim3(256), 0, st, fin, fin_stride, pw, ph, mul, sx, sy, R0, R1, R_stride, w,
+                           h, tm, scale, fout, fout_stride);
     else if (mode == 1)
-        hipLaunchKernelGGL((k_sweep_rc<6, 1>), dim3(nb), dim3(256), 0, st, fin, fin_stride, pw, ph, mul, sx, sy, R0, R1, R_stride, w,
-                           h, tiles_x, per_img, n_tiles, scale, fout, fout_stride);
+        hipLaunchKernelGGL((k_sweep_rc<6, 1>), nb, dim3(256), 0, st, fin, fin_stride, pw, ph, mul, sx, sy, R0, R1, R_stride, w,
+                           h, tm, scale, fout, fout_stride);
     else
-        hipLaunchKernelGGL((k_sweep_rc<6, 2>), dim3(nb), dim3(256), 0, st, fin, fin_stride, pw, ph, mul, sx, sy, R0, R1, R_stride, w,
-                           h, tiles_x, per_img, n_tiles, scale, fout, fout_stride);
+        hipLaunchKernelGGL((k_sweep_rc<6, 2>), nb, dim3(256), 0, st, fin, fin_stride, pw, ph, mul, sx, sy, R0, R1, R_stride, w,
+                           h, tm, scale, fout, fout_stride);
     return true;
 }

@@ -1,9 +1,11 @@
 """The single-precision screen of the phi / mask kernel, bounded by test.
 
-When phi itself is not requested (the configuration bench.py times) k_phi_mask decides most pixels in float32 in the
-arccos-ARGUMENT domain (phi > T  <=>  arg < cos T) and sends only the pixels inside its guard bands (2e-5 around cos 15 deg,
-1e-4 around the cosine of the dynamic threshold, 1e-5 relative around the two magnitude gates) down the exact double path.
-The claim is that the masks cannot change.  These tests plant pixels at +-{1e-8 ... 1e-3} (arccos-argument units) around
+When phi itself is not requested (the configuration bench.py times) k_phi_mask decides most pixels in float32 -- in the
+tangent form  phi > T  <=>  dot <= 0 or |cross| > tan(T) dot  for thresholds up to 17 degrees (margin 4e-6 |f||d|(1 + tan T),
+i.e. ~2e-4 degrees), in the arccos-argument form  arg < cos T  (band 1e-4) for larger dynamic thresholds, 1e-5 relative around
+the two magnitude gates -- and sends only the pixels inside those bands down the exact double path.
+The claim is that the masks cannot change.  These tests plant pixels at +-{1e-10 ... 0.1} degrees and +-{1e-8 ... 1e-3}
+(arccos-argument units) around
 every decision -- the fixed 15 degree threshold, the dynamic threshold 0.75 + 8/mag over mag in [0.5, 200] (and, with other
 parameters, all the way to 178 degrees), both magnitude gates -- for an FoE inside the image, on a pixel centre, and 1e4 px
 outside it, and require the screened masks (float32 flow, the kernel instance of the fused path, through mav_stage_phi_mask;
@@ -18,6 +20,8 @@ from oracle import foe_oracle as fo
 pytestmark = pytest.mark.gpu
 W, H = 640, 480
 DELTAS = np.array([0.0, 1e-8, 3e-8, 1e-7, 3e-7, 1e-6, 3e-6, 1e-5, 1.9e-5, 2.1e-5, 3e-5, 6e-5, 9.5e-5, 1.05e-4, 1.5e-4, 3e-4, 1e-3])
+# the same in the ANGLE domain (degrees): the tangent-form screen's band is ~2e-4 degrees wide at any threshold
+EPS_DEG = np.array([0.0, 1e-10, 1e-9, 1e-8, 1e-7, 3e-7, 1e-6, 3e-6, 1e-5, 3e-5, 1e-4, 2e-4, 3e-4, 1e-3, 1e-2, 0.1])
 
 
 def planted_field(foe, rng, dyn_a=0.25, dyn_b=0.5, dyn_c=8.0, fixed_deg=15.0, mag_lo=0.5, mag_hi=200.0, gates=(0.5, 1.0)):
@@ -36,8 +40,10 @@ def planted_field(foe, rng, dyn_a=0.25, dyn_b=0.5, dyn_c=8.0, fixed_deg=15.0, ma
     with np.errstate(all="ignore"):
         T = np.where(kind == 0, fixed_deg, dyn_a + dyn_b + dyn_c / mag)
     T = np.clip(T, 0.0, 179.9)
-    arg = np.cos(np.deg2rad(T)) + np.where(kind < 2, delta, rng.uniform(-0.5, 0.5, (H, W)))
-    ang = np.arccos(np.clip(arg, -1.0, 1.0))
+    in_angle = rng.random((H, W)) < 0.5               # half the threshold pixels are offset in degrees, half in arccos-argument units
+    arg = np.cos(np.deg2rad(T)) + np.where(kind < 2, np.where(in_angle, 0.0, delta), rng.uniform(-0.5, 0.5, (H, W)))
+    eps = rng.choice(EPS_DEG, (H, W)) * rng.choice([-1.0, 1.0], (H, W))
+    ang = np.arccos(np.clip(arg, -1.0, 1.0)) + np.deg2rad(np.where((kind < 2) & in_angle, eps, 0.0))
     a = theta_r + side * ang
     flow = np.stack([mag * np.cos(a), mag * np.sin(a)], axis=-1)
     return flow
