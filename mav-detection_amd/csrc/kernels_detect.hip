@@ -276,14 +276,13 @@ static __device__ __forceinline__ double phi_exact(double u, double v, double d2
     return acos(arg) * (180.0 / 3.141592653589793238462643383279502884);
 }
 
-// One pixel of the phi / mask stage: screen in f32, exact double path inside the guard bands (or when phi is wanted).
-static __device__ __forceinline__ void phi_pixel(double u, double v, int x, int y, double foex, double foey, bool notsky,
-                                                 const mav_thr_params& thr, const PhiScreen& scr, bool* fix_out, bool* dyn_out,
-                                                 double* ph_out, bool* have_ph)
+// Single-precision screen of one pixel of the phi / mask stage.  Returns true when both verdicts are certain (then *fix_out /
+// *dyn_out hold them); false sends the pixel to phi_pixel_exact().
+static __device__ __forceinline__ bool phi_pixel_screen(float uf, float vf, int x, int y, double foex, double foey, bool notsky,
+                                                        const PhiScreen& scr, bool* fix_out, bool* dyn_out)
 {
     const double d2x = (double)x - foex, d2y = (double)y - foey;
-    *have_ph = false;
-    if (scr.enabled) {
+    {
         // Single-precision screen.  For a threshold T below 90 degrees
         //     phi > T   <=>   dot <= 0  or  |cross| > tan(T) * dot        (dot = f . d, cross = f x d, d = p - FoE),
         // and this form is well conditioned exactly where the thresholds live (a few degrees): in float32 dot and |cross| are
@@ -293,7 +292,7 @@ static __device__ __forceinline__ void phi_pixel(double u, double v, int x, int 
         // with a 1e-4 band, is ill conditioned at small T -- d arg = sin T dT -- and sent every pixel within ~0.15 degrees of a
         // 2-degree threshold down the double path: most waves of a real flow field.)  The cosine form remains for dynamic
         // thresholds above 17 degrees (|flow| < 0.5, reachable only with non-default gates).  Gates: 1e-5 relative around both.
-        const float uf = (float)u, vf = (float)v, dxf = (float)d2x, dyf = (float)d2y;
+        const float dxf = (float)d2x, dyf = (float)d2y;
         const float m2 = uf * uf + vf * vf, dd = dxf * dxf + dyf * dyf;
         const float prod2 = m2 * dd;
         const float dot = uf * dxf + vf * dyf;
@@ -330,18 +329,28 @@ static __device__ __forceinline__ void phi_pixel(double u, double v, int x, int 
             } else
                 sure = sure && T > 181.f;                         // phi <= 180 < T: certainly false
         }
-        if (sure) { *fix_out = f; *dyn_out = d; return; }
+        *fix_out = f; *dyn_out = d;
+        return sure;
     }
+}
+
+// The exact path of one pixel: double arithmetic in numpy's order (phi_exact) and the literal threshold block.  Out of line on
+// purpose: only ~1e-5 of the pixels come here when the screen is on, and sixteen inlined copies of the double sqrt / divide /
+// acos sequences made the kernel 69 KB of code -- more than the instruction cache two CUs share.
+// (everything by value, result in registers: no stack frame, the kernel needs no scratch memory)
+struct PhiVerdict { double ph; unsigned bits; };     // bits: 1 = fixed mask, 2 = dynamic mask
+static __device__ __noinline__ PhiVerdict phi_pixel_exact(double u, double v, double d2x, double d2y, int notsky, double fixed_deg,
+                                                          double fixed_min_mag, double dyn_min_mag, double dyn_a, double dyn_b,
+                                                          double dyn_c)
+{
     double fm;
     const double ph = phi_exact(u, v, d2x, d2y, &fm);
-    const double t = thr.dyn_b + thr.dyn_c / fm;
-    const bool hi = ph > (thr.dyn_a + t);
-    const bool lo = ph < (thr.dyn_a - t);
-    *dyn_out = (fm > thr.dyn_min_mag) && notsky && (lo || hi);
-    const double gated = ((fm > thr.fixed_min_mag) && notsky) ? ph : 0.0;
-    *fix_out = gated > thr.fixed_deg;
-    *ph_out = ph;
-    *have_ph = true;
+    const double t = dyn_b + dyn_c / fm;
+    const bool hi = ph > (dyn_a + t);
+    const bool lo = ph < (dyn_a - t);
+    const bool dyn = (fm > dyn_min_mag) && notsky && (lo || hi);
+    const double gated = ((fm > fixed_min_mag) && notsky) ? ph : 0.0;
+    return PhiVerdict{ph, (gated > fixed_deg ? 1u : 0u) | (dyn ? 2u : 0u)};
 }
 
 // One pixel of a frame-0 pair: get_phi (focus_of_expansion.py:163-177) and the threshold block (processor.py:333-341) as numpy
@@ -350,10 +359,10 @@ static __device__ __forceinline__ void phi_pixel(double u, double v, int x, int 
 // float32 operations, rad2deg multiplies by 180f / pif.  No contraction (this file is built with -ffp-contract=off).
 // arccos: the correctly rounded float32 value (double acos, rounded once).
 struct ThrF32 { float fixed_deg, fixed_min_mag, dyn_min_mag, dyn_a, dyn_b, dyn_c; };
-static __device__ __forceinline__ void phi_pixel_f32(float u, float v, int x, int y, double foex, double foey, bool notsky,
-                                                     const ThrF32& t, bool* fix_out, bool* dyn_out, float* ph_out)
+static __device__ __noinline__ PhiVerdict phi_pixel_f32(float u, float v, float d2x, float d2y, int notsky, float fixed_deg,
+                                                        float fixed_min_mag, float dyn_min_mag, float dyn_a, float dyn_b, float dyn_c)
 {
-    const float d2x = (float)((double)x - foex), d2y = (float)((double)y - foey);
+    const ThrF32 t{fixed_deg, fixed_min_mag, dyn_min_mag, dyn_a, dyn_b, dyn_c};
     const float fm = sqrtf(u * u + v * v);
     const float dist = sqrtf(d2x * d2x + d2y * d2y);
     const float prod = fm * dist;
@@ -367,10 +376,9 @@ static __device__ __forceinline__ void phi_pixel_f32(float u, float v, int x, in
     const float tt = t.dyn_b + t.dyn_c / fm;
     const bool hi = ph > (t.dyn_a + tt);
     const bool lo = ph < (t.dyn_a - tt);
-    *dyn_out = (fm > t.dyn_min_mag) && notsky && (lo || hi);
+    const bool dyn = (fm > t.dyn_min_mag) && notsky && (lo || hi);
     const float gated = ((fm > t.fixed_min_mag) && notsky) ? ph : 0.f;
-    *fix_out = gated > t.fixed_deg;
-    *ph_out = ph;
+    return PhiVerdict{(double)ph, (gated > t.fixed_deg ? 1u : 0u) | (dyn ? 2u : 0u)};
 }
 
 // VEC = 4: one thread = 4 consecutive pixels x 4 rows (W % 4 == 0): float4 / double2 row loads, uchar4 mask stores;
@@ -388,65 +396,85 @@ __global__ __launch_bounds__(256) void k_phi_mask(const FlowT* __restrict__ flow
     const FlowT* fl = flow + b * npx * 2;
     const DerotParams* dp = derot ? derot + b : nullptr;
     const bool f32_pair = std::is_same<FlowT, float>::value && dp && dp->mode == MAV_PAIR_FRAME0;
-    const ThrF32 thr32{(float)thr.fixed_deg, (float)thr.fixed_min_mag, (float)thr.dyn_min_mag, (float)thr.dyn_a, (float)thr.dyn_b,
-                       (float)thr.dyn_c};
     const double foex = foe[2 * b], foey = foe[2 * b + 1];
     int bx0 = INT_MAX, by0 = INT_MAX, bx1 = -1, by1 = -1;
     double pmax = 0.0;
     const int xb = (blockIdx.x * 64 + lane) * VEC;
     const bool colok = xb < W;                            // lanes past the right edge stay for the wave reductions below
     const int xld = colok ? xb : 0;
-    // every flow vector and sky word of the thread is requested before the first pixel is evaluated: the per-pixel code
-    // branches (exact path inside the guard bands), and loads left between those branches would be one round trip each
+    const int yb = blockIdx.y * 16 + wv * 4;
+    // Pass 1 (every pixel, compact straight-line code): all flow vectors and sky words of the thread are requested up front, then
+    // each pixel is screened in float32; bit 4r + j of fixb / dynb holds its verdicts, of `todo` that it still needs the exact path
+    // (inside a guard band, derotated, screen off, or a frame-0 pair).
     decltype(flow_raw(fl, W, 0, 0)) raw[4][VEC];
     uint32_t skw[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        const int yc = min(blockIdx.y * 16 + wv * 4 + r, H - 1);          // rows past the bottom: re-read the last row, never stored
+        const int yc = min(yb + r, H - 1);                // rows past the bottom: re-read the last row, never stored
 #pragma unroll
         for (int j = 0; j < VEC; j++) raw[r][j] = flow_raw(fl, W, yc, xld + j);
         const size_t oc = b * npx + (size_t)yc * W + xld;
         skw[r] = !sky ? 0u : (VEC == 4 ? *(const uint32_t*)(sky + oc) : (uint32_t)sky[oc]);
     }
+    unsigned fixb = 0u, dynb = 0u, todo = 0u;
+    const bool screen = scr.enabled && !f32_pair;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        const int y = blockIdx.y * 16 + wv * 4 + r;
-        if (y >= H || !colok) continue;
-        const size_t o = b * npx + (size_t)y * W + xb;
-        uint8_t sk[VEC], mf[VEC], md[VEC];
-        if (VEC == 4) {
-            const uint32_t s4 = skw[r];
-            sk[0] = s4 & 255u; sk[1 % VEC] = (s4 >> 8) & 255u; sk[2 % VEC] = (s4 >> 16) & 255u; sk[3 % VEC] = s4 >> 24;
-        } else
-            sk[0] = (uint8_t)skw[r];
+        if (yb + r >= H || !colok) continue;
 #pragma unroll
         for (int j = 0; j < VEC; j++) {
-            const int x = xb + j;
-            bool fix, dyn, have;
-            double ph = 0.0;
-            if (f32_pair) {
-                float ph32;
-                phi_pixel_f32((float)raw[r][j].x, (float)raw[r][j].y, x, y, foex, foey, sk[j] == 0, thr32, &fix, &dyn, &ph32);
-                ph = (double)ph32;
-                have = true;
-            } else {
-                double u, v;
-                derot_apply(raw[r][j], dp, W, H, y, x, &u, &v);
-                phi_pixel(u, v, x, y, foex, foey, sk[j] == 0, thr, scr, &fix, &dyn, &ph, &have);
+            const unsigned bit = 1u << (4 * r + j);
+            const bool notsky = ((skw[r] >> (8 * j)) & 255u) == 0u;
+            bool fix = false, dyn = false, sure = false;
+            if (screen) {
+                double u, v;                              // derotation (a wave-uniform branch) in double, then the float32 screen
+                derot_apply(raw[r][j], dp, W, H, yb + r, xb + j, &u, &v);
+                sure = phi_pixel_screen((float)u, (float)v, xb + j, yb + r, foex, foey, notsky, scr, &fix, &dyn);
             }
-            if (have) {
-                if (phi_out) phi_out[o + j] = ph;
-                pmax = ph > pmax ? ph : pmax;
-            }
-            mf[j] = fix ? 1 : 0; md[j] = dyn ? 1 : 0;
-            if (fix) { bx0 = min(bx0, x); bx1 = max(bx1, x); by0 = min(by0, y); by1 = max(by1, y); }
+            if (!sure) todo |= bit;
+            else { if (fix) fixb |= bit; if (dyn) dynb |= bit; }
         }
+    }
+    // Pass 2 (rare when the screen is on): the exact path, out of line, one pixel at a time; the pixel's inputs are re-read
+    // (L1 / L2 hits) instead of being indexed out of registers.
+    for (unsigned m = todo; m; m &= m - 1u) {
+        const int k = __ffs(m) - 1, r = k >> 2, j = k & 3;
+        const int x = xb + j, y = yb + r;
+        const size_t o = b * npx + (size_t)y * W + x;
+        const int notsky = !sky || sky[o] == 0;
+        const auto rv = flow_raw(fl, W, y, x);
+        const double d2x = (double)x - foex, d2y = (double)y - foey;
+        PhiVerdict pv;
+        if (f32_pair)       // diff2 is a float32 array in the reference: the double coordinate difference is rounded into it
+            pv = phi_pixel_f32((float)rv.x, (float)rv.y, (float)d2x, (float)d2y, notsky, (float)thr.fixed_deg, (float)thr.fixed_min_mag,
+                               (float)thr.dyn_min_mag, (float)thr.dyn_a, (float)thr.dyn_b, (float)thr.dyn_c);
+        else {
+            double u, v;
+            derot_apply(rv, dp, W, H, y, x, &u, &v);
+            pv = phi_pixel_exact(u, v, d2x, d2y, notsky, thr.fixed_deg, thr.fixed_min_mag, thr.dyn_min_mag, thr.dyn_a, thr.dyn_b, thr.dyn_c);
+        }
+        if (phi_out) phi_out[o] = pv.ph;
+        pmax = pv.ph > pmax ? pv.ph : pmax;
+        if (pv.bits & 1u) fixb |= 1u << k;
+        if (pv.bits & 2u) dynb |= 1u << k;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int y = yb + r;
+        if (y >= H || !colok) continue;
+        const size_t o = b * npx + (size_t)y * W + xb;
+        const unsigned f4 = (fixb >> (4 * r)) & 15u, d4 = (dynb >> (4 * r)) & 15u;
         if (VEC == 4) {
-            if (mfix) *(uint32_t*)(mfix + o) = mf[0] | (mf[1 % VEC] << 8) | (mf[2 % VEC] << 16) | ((uint32_t)mf[3 % VEC] << 24);
-            if (mdyn) *(uint32_t*)(mdyn + o) = md[0] | (md[1 % VEC] << 8) | (md[2 % VEC] << 16) | ((uint32_t)md[3 % VEC] << 24);
+            // bit j -> byte j (0 / 1): spread the nibble over a dword
+            if (mfix) *(uint32_t*)(mfix + o) = (f4 & 1u) | ((f4 & 2u) << 7) | ((f4 & 4u) << 14) | ((f4 & 8u) << 21);
+            if (mdyn) *(uint32_t*)(mdyn + o) = (d4 & 1u) | ((d4 & 2u) << 7) | ((d4 & 4u) << 14) | ((d4 & 8u) << 21);
         } else {
-            if (mfix) mfix[o] = mf[0];
-            if (mdyn) mdyn[o] = md[0];
+            if (mfix) mfix[o] = (uint8_t)(f4 & 1u);
+            if (mdyn) mdyn[o] = (uint8_t)(d4 & 1u);
+        }
+        if (f4) {
+            bx0 = min(bx0, xb + __ffs(f4) - 1); bx1 = max(bx1, xb + 31 - __clz(f4));
+            by0 = min(by0, y); by1 = max(by1, y);
         }
     }
     wave_box_commit(bx0, by0, bx1, by1, box_acc + 4 * b);

@@ -24,11 +24,11 @@ static __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v <
 // is 60 tiles and without strips the reuse distance exceeds the L2.  Speed only: every tile is computed exactly once and
 // nothing depends on the order.  Grid = n_tiles rounded up to a multiple of 8.
 // ------------------------------------------------------------------------------------------------------------
-struct TileMap { int tiles_x, tiles_y, per_img, n_tiles, strip_w; };
+struct TileMap { int tiles_x, tiles_y, per_img, n_tiles, strip_w, xcd; };   // xcd = 0: plain row-major order (A/B switch)
 static __device__ __forceinline__ bool tile_of_block(const TileMap& tm, int* s, int* tx, int* ty)
 {
     const int per = ((int)gridDim.x + 7) >> 3;
-    const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    const int tile = tm.xcd ? (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     if (tile >= tm.n_tiles) return false;
     const int img = tile / tm.per_img;
     int tr = tile - img * tm.per_img;
@@ -42,9 +42,11 @@ static __device__ __forceinline__ bool tile_of_block(const TileMap& tm, int* s, 
     return true;
 }
 static int g_strip_override = -1;                                // MAVFLOW_STRIP: tuning experiments only
-static TileMap make_tile_map(int w, int h, int G, int tile_w, int tile_h)
+static TileMap make_tile_map(int w, int h, int G, int tile_w, int tile_h, const char* ab_env = nullptr)
 {
     TileMap tm;
+    tm.xcd = 1;
+    if (ab_env) { const char* e = getenv(ab_env); if (e) tm.xcd = atoi(e) != 0; }
     tm.tiles_x = (w + tile_w - 1) / tile_w;
     tm.tiles_y = (h + tile_h - 1) / tile_h;
     tm.per_img = tm.tiles_x * tm.tiles_y;
@@ -401,7 +403,7 @@ void launch_polyexp(hipStream_t st, const float* I, size_t I_stride, int G, int 
 {
     const int n = pc.n;
     const size_t lds = sizeof(float) * ((size_t)(PX + 2 * n) * (PY + 2 * n) + 3 * (size_t)PY * (PX + 2 * n));
-    const TileMap tm = make_tile_map(w, h, G, PX, PY);
+    const TileMap tm = make_tile_map(w, h, G, PX, PY, "MAVFLOW_XCD_POLY");
     const dim3 grid(tile_grid(tm));
     if (n == 8)
         hipLaunchKernelGGL(k_polyexp<8>, grid, dim3(256), lds, st, I, I_stride, w, h, pc, tm, R, R_stride);
@@ -572,7 +574,7 @@ __global__ __launch_bounds__(256) void k_update_matrices(const float* __restrict
 void launch_update_matrices(hipStream_t st, const float* R0, const float* R1, size_t R_stride, const float* flow_prev,
                             size_t fp_stride, int pw, int ph, float mul, int G, int w, int h, float* M, size_t M_stride)
 {
-    const TileMap tm = make_tile_map(w, h, G, 64, 16);
+    const TileMap tm = make_tile_map(w, h, G, 64, 16, "MAVFLOW_XCD_UPD");
     const dim3 grid(tile_grid(tm));
     if (flow_prev)
         hipLaunchKernelGGL(k_update_matrices<1>, grid, dim3(256), 0, st, R0, R1, R_stride, flow_prev, fp_stride, pw, ph, mul,
@@ -772,7 +774,8 @@ __global__ __launch_bounds__(256) void k_blur_iter_fast(const float* __restrict_
                                                         size_t M_stride, const float* __restrict__ R0,
                                                         const float* __restrict__ R1, size_t R_stride, int w, int h,
                                                         TileMap tm, float scale,
-                                                        int do_update, int store_flow, float* __restrict__ flow, size_t f_stride)
+                                                        int do_update, int store_flow, float* __restrict__ flow, size_t f_stride,
+                                                        int stagger)
 {
     constexpr int EXT_X = FT_X + 2 * M_T;              // 76
     constexpr int EXT_Y = FT_Y + 2 * M_T;              // 28
@@ -785,6 +788,10 @@ __global__ __launch_bounds__(256) void k_blur_iter_fast(const float* __restrict_
     const int lane = tid & 63, wv = tid >> 6;
     int s, tx, ty;                                       // XCD-aware tile order, see tile_of_block()
     if (!tile_of_block(tm, &s, &tx, &ty)) return;
+    // EXPERIMENT (MAVFLOW_STAGGER): all workgroups of the first residency round start together and run their memory and
+    // arithmetic phases in lockstep; delaying every other resident slot of a CU by part of a tile time interleaves them.
+    if (stagger > 0 && blockIdx.x < 1280u && ((blockIdx.x >> 8) & 1u))
+        for (int i = 0; i < stagger; i++) __builtin_amdgcn_s_sleep(32);
     const int x0 = tx * FT_X, y0 = ty * FT_Y;
     const size_t npx = (size_t)w * h;
     const float* Min = M_in + (size_t)s * M_stride;
@@ -1096,14 +1103,16 @@ void launch_blur_iter(hipStream_t st, const float* M_in, float* M_out, size_t M_
                         aligned16(M_out) && aligned16(R0) && aligned16(R1) && aligned16(flow);
     if (m == 6 && vec_ok) {
         const TileMap tm = make_tile_map(w, h, G, FT_X, FT_Y);
+        static int stagger = -1;
+        if (stagger < 0) { const char* e = getenv("MAVFLOW_STAGGER"); stagger = e ? atoi(e) : 0; }
         hipLaunchKernelGGL(k_blur_iter_fast<6>, dim3(tile_grid(tm)), dim3(256), 0, st, M_in, M_out, M_stride, R0, R1, R_stride, w, h,
-                           tm, scale, do_update, store_flow, flow, f_stride);
+                           tm, scale, do_update, store_flow, flow, f_stride, stagger);
         return;
     }
     if (m == 6 && f_stride % 2 == 0 && ((uintptr_t)flow & 7) == 0) {    // any width / alignment: relaxed form of the same kernel
         const TileMap tm = make_tile_map(w, h, G, FT_X, FT_Y);
         hipLaunchKernelGGL((k_blur_iter_fast<6, false>), dim3(tile_grid(tm)), dim3(256), 0, st, M_in, M_out, M_stride, R0, R1, R_stride,
-                           w, h, tm, scale, do_update, store_flow, flow, f_stride);
+                           w, h, tm, scale, do_update, store_flow, flow, f_stride, 0);
         return;
     }
     iter_geometry(m, &ext, &pitch, &plane);

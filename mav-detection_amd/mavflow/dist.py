@@ -57,3 +57,20 @@ def allgather_numpy(dist, records: np.ndarray) -> np.ndarray:
     local = torch.from_numpy(np.ascontiguousarray(records).view(np.uint8).reshape(-1).copy())
     out = allgather_records(dist, local)
     return out.numpy().view(records.dtype).reshape(-1)
+
+
+def allgather_pairs(dist, records: np.ndarray, n_items: int) -> np.ndarray:
+    """All n_items per-pair records in PAIR order from every rank's shard (`records` = this rank's shard(n_items, rank, world)
+    slice, possibly empty).  Ragged totals: every rank pads its shard to ceil(n_items / world) records so that the collective
+    stays ONE fixed-size all-gather, and the padding is dropped on arrival using the same shard table."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    lo, hi = shard(n_items, rank, world)
+    if len(records) != hi - lo:
+        raise ValueError(f"rank {rank} holds {len(records)} records, its shard of {n_items} is [{lo}, {hi})")
+    per = -(-n_items // world) if n_items else 0
+    if per == 0:
+        return records[:0].copy()
+    padded = np.zeros(per, records.dtype)
+    padded[:hi - lo] = records
+    allrec = allgather_numpy(dist, padded).reshape(world, per)
+    return np.concatenate([allrec[r, :shard(n_items, r, world)[1] - shard(n_items, r, world)[0]] for r in range(world)])

@@ -59,3 +59,41 @@ for W, H in ((640, 480), (1280, 720), (1920, 1080)):
         t0 = time.perf_counter(); ctx.process_batch(prev, nxt, smp, want_flow=False); t.append(time.perf_counter() - t0)
     stats("mav_process_batch (host, no flow out)", t)
     ctx.close()
+
+# ---- the reference-shaped loop at 1080p: one Processor.run_detection iteration against process_batch(batch = 1) ----
+import logging
+from mavflow.processor import Processor, SyntheticDataset
+from mavflow.run_config import RunConfig
+
+W, H = 1920, 1080
+print(f"{W}x{H}: Processor loops, per iteration", flush=True)
+ctx = _lib.Context(W, H, 1)
+prev, nxt = synth.make_batch(W, H, 1, distinct=1)
+smp = np.stack([synth.foe_samples(W, H, 0)])
+flow = ctx.farneback(prev, nxt)
+for fn, name in ((lambda: ctx.process_batch(prev, nxt, smp, want_flow=False), "process_batch(batch=1), masks out"),
+                 (lambda: ctx.process_batch(prev, nxt, smp, want_flow=True), "process_batch(batch=1), flow + masks out"),
+                 (lambda: ctx.detect(flow, smp), "detect(batch=1): f32 flow in, masks out")):
+    for _ in range(3):
+        fn()
+    t = []
+    for _ in range(min(CALLS, 50)):
+        t0 = time.perf_counter(); fn(); t.append(time.perf_counter() - t0)
+    stats(name, t)
+ctx.close()
+for use_fb, label in ((True, "flow seam = Farneback on the GPU"), (False, "flow seam = host array (.flo-like)")):
+    N = 12
+    for loop in ("run_detection", "run_detection_staged", "run_detection_batched"):
+        ds = SyntheticDataset(W, H, N, use_farneback=use_fb)
+        for i in range(N):
+            ds._pair(i)                                   # frame synthesis is not part of the loop being timed
+        cfg = RunConfig(logging.getLogger("t"), ds, "", False, False, False, True, False, False, "FLOW_FOE_CLUSTERING")
+        p = Processor(cfg)
+        warm = Processor(RunConfig(logging.getLogger("t"), ds, "", False, False, False, True, False, False, "FLOW_FOE_CLUSTERING"))
+        warm.dataset = ds
+        getattr(warm, loop)() if loop != "run_detection_batched" else warm.run_detection_batched(batch=1)
+        t0 = time.perf_counter()
+        getattr(p, loop)() if loop != "run_detection_batched" else p.run_detection_batched(batch=1)
+        dt = (time.perf_counter() - t0) / (N - 1)
+        print(f"  {label:38s} {loop:24s} {dt * 1e3:8.3f} ms per frame", flush=True)
+        ds.release()
