@@ -403,7 +403,9 @@ void launch_polyexp(hipStream_t st, const float* I, size_t I_stride, int G, int 
 {
     const int n = pc.n;
     const size_t lds = sizeof(float) * ((size_t)(PX + 2 * n) * (PY + 2 * n) + 3 * (size_t)PY * (PX + 2 * n));
-    const TileMap tm = make_tile_map(w, h, G, PX, PY, "MAVFLOW_XCD_POLY");
+    TileMap tm = make_tile_map(w, h, G, PX, PY);
+    tm.xcd = 0;        // plain row-major order: measured 3 % faster here than the XCD-banded order (the halo re-reads that miss
+                       // L2 hit the Infinity Cache, which all XCDs share; the kernel is VALU / write bound, not read bound)
     const dim3 grid(tile_grid(tm));
     if (n == 8)
         hipLaunchKernelGGL(k_polyexp<8>, grid, dim3(256), lds, st, I, I_stride, w, h, pc, tm, R, R_stride);
@@ -511,85 +513,49 @@ static __device__ __forceinline__ float2 upsample_flow(const float* __restrict__
 
 // Initial M of a layer.  flow = 0 (top layer), resize(prevFlow)*mul evaluated inline (lower layers), or an
 // explicit flow field (stage hook).  The upsampled flow is never written: the first blur sweep overwrites it.
-// 64 x 16 pixel tile per workgroup in the XCD-aware order of tile_of_block(): lane = pixel column, wave v owns tile rows
-// 4v .. 4v+3, so a wave's R0 loads, R1 gathers and M stores are row-contiguous, the 2x2 gather rows of vertically adjacent
-// pixels are re-used from L1 / the XCD's L2 (a 64 x 4 block per workgroup on a 2-D grid fetched them 1.5x), all 20 R0 loads of
-// a thread are requested up front and the gathers of two pixels are in flight together (gather_issue / update_finish below).
-struct GatherPx;
-static __device__ __forceinline__ void gather_issue(const float* __restrict__ R1p, size_t npx, int w, int h, int x, int y, float dx,
-                                                    float dy, GatherPx& g);
-static __device__ __forceinline__ void update_finish(const float q[5], const GatherPx& g, int w, int h, int x, int y, float dx,
-                                                     float dy, float out[5]);
-struct GatherPx {
-    float p00[5], p01[5], p10[5], p11[5];
-    float fx, fy;
-    bool inside;
-};
+// One thread per pixel, 64 x 4 pixels per workgroup on a plain 2-D grid.  (Measured alternative, not kept: 64 x 16 tiles in the
+// XCD-aware order with two gathers in flight per thread -- L2 absorbed the gather rows, the kernel ran 5 % slower: its reads
+// that miss L2 are served by the Infinity Cache anyway, and the taller tile halves the number of workgroups in flight.)
 template <int MODE>  // 0 zero, 1 upsample, 2 explicit
 __global__ __launch_bounds__(256) void k_update_matrices(const float* __restrict__ R0, const float* __restrict__ R1,
                                                          size_t R_stride, const float* __restrict__ fsrc, size_t f_stride,
                                                          int pw, int ph, float mul, double scale_x, double scale_y, int w,
-                                                         int h, TileMap tm, float* __restrict__ M, size_t M_stride)
+                                                         int h, float* __restrict__ M, size_t M_stride)
 {
-    int s, tx, ty;
-    if (!tile_of_block(tm, &s, &tx, &ty)) return;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int x = tx * 64 + lane, xc = min(x, w - 1);
-    const int yb = ty * 16 + wv * 4;
-    const size_t npx = (size_t)w * h;
-    const float* R0p = R0 + (size_t)s * R_stride;
-    const float* R1p = R1 + (size_t)s * R_stride;
-    float* Mp = M + (size_t)s * M_stride;
-    float q[4][5];
-    float2 f[4];
-    int ys[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        ys[j] = min(yb + j, h - 1);
-        const size_t idx = (size_t)ys[j] * w + xc;
-#pragma unroll
-        for (int c = 0; c < 5; c++) q[j][c] = R0p[c * npx + idx];
-        if (MODE == 1) f[j] = upsample_flow(fsrc + (size_t)s * f_stride, pw, ph, mul, scale_x, scale_y, xc, ys[j]);
-        else if (MODE == 2) f[j] = *(const float2*)(fsrc + (size_t)s * f_stride + idx * 2);
-        else f[j] = make_float2(0.f, 0.f);
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const int s = blockIdx.z;
+    float dx = 0.f, dy = 0.f;
+    if (MODE == 1) {
+        const float2 f = upsample_flow(fsrc + (size_t)s * f_stride, pw, ph, mul, scale_x, scale_y, x, y);
+        dx = f.x; dy = f.y;
+    } else if (MODE == 2) {
+        const float2 f = *(const float2*)(fsrc + (size_t)s * f_stride + ((size_t)y * w + x) * 2);
+        dx = f.x; dy = f.y;
     }
-#pragma unroll
-    for (int jb = 0; jb < 4; jb += 2) {
-        GatherPx g[2];
-#pragma unroll
-        for (int jj = 0; jj < 2; jj++) gather_issue(R1p, npx, w, h, xc, ys[jb + jj], f[jb + jj].x, f[jb + jj].y, g[jj]);
-#pragma unroll
-        for (int jj = 0; jj < 2; jj++) {
-            float o[5];
-            update_finish(q[jb + jj], g[jj], w, h, xc, ys[jb + jj], f[jb + jj].x, f[jb + jj].y, o);
-            if (x < w && yb + jb + jj < h) {
-                const size_t idx = (size_t)ys[jb + jj] * w + xc;
-#pragma unroll
-                for (int c = 0; c < 5; c++) Mp[c * npx + idx] = o[c];
-            }
-        }
-    }
+    update_px(R0 + (size_t)s * R_stride, R1 + (size_t)s * R_stride, (size_t)w * h, w, h, x, y, dx, dy,
+              M + (size_t)s * M_stride);
 }
 
 void launch_update_matrices(hipStream_t st, const float* R0, const float* R1, size_t R_stride, const float* flow_prev,
                             size_t fp_stride, int pw, int ph, float mul, int G, int w, int h, float* M, size_t M_stride)
 {
-    const TileMap tm = make_tile_map(w, h, G, 64, 16, "MAVFLOW_XCD_UPD");
-    const dim3 grid(tile_grid(tm));
+    dim3 grid((w + 63) / 64, (h + 3) / 4, G);
     if (flow_prev)
         hipLaunchKernelGGL(k_update_matrices<1>, grid, dim3(256), 0, st, R0, R1, R_stride, flow_prev, fp_stride, pw, ph, mul,
-                           (double)pw / w, (double)ph / h, w, h, tm, M, M_stride);
+                           (double)pw / w, (double)ph / h, w, h, M, M_stride);
     else
         hipLaunchKernelGGL(k_update_matrices<0>, grid, dim3(256), 0, st, R0, R1, R_stride, (const float*)nullptr, (size_t)0,
-                           0, 0, 0.f, 0.0, 0.0, w, h, tm, M, M_stride);
+                           0, 0, 0.f, 0.0, 0.0, w, h, M, M_stride);
 }
 
 void launch_update_matrices_flow(hipStream_t st, const float* R0, const float* R1, size_t R_stride, const float* flow,
                                  size_t f_stride, int G, int w, int h, float* M, size_t M_stride)
 {
-    const TileMap tm = make_tile_map(w, h, G, 64, 16);
-    hipLaunchKernelGGL(k_update_matrices<2>, dim3(tile_grid(tm)), dim3(256), 0, st, R0, R1, R_stride, flow, f_stride, 0, 0, 0.f, 0.0,
-                       0.0, w, h, tm, M, M_stride);
+    dim3 grid((w + 63) / 64, (h + 3) / 4, G);
+    hipLaunchKernelGGL(k_update_matrices<2>, grid, dim3(256), 0, st, R0, R1, R_stride, flow, f_stride, 0, 0, 0.f, 0.0, 0.0,
+                       w, h, M, M_stride);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -714,6 +680,11 @@ __global__ __launch_bounds__(256) void k_blur_iter_generic(const float* __restri
 #define FT_X 64
 #define FT_Y 16
 
+struct GatherPx {
+    float p00[5], p01[5], p10[5], p11[5];
+    float fx, fy;
+    bool inside;
+};
 // request the 2x2 neighbourhood of the 5 R1 planes around (x + dx, y + dy); out-of-image taps read a clamped address
 static __device__ __forceinline__ void gather_issue(const float* __restrict__ R1p, size_t npx, int w, int h, int x, int y, float dx,
                                                     float dy, GatherPx& g)
