@@ -193,9 +193,18 @@ struct mav_ctx {
     PolyCoef pc;
     // workspace (group slots)
     size_t n0 = 0, n1 = 0;
-    float *Htmp = nullptr;           // scratch of the separable blur+resize: group x H x (widest coarse layer)
+    // Workspace of `group` slots, in TWO sets when a batch spans more than one group: while the finest layer's sweeps of
+    // group i run on the compute stream out of one set, group i + 1's pyramid and polynomial expansions are built on the
+    // preparation stream into the other (mav_farneback_dev).
+    struct WorkSet {
+        float *Htmp = nullptr;       // scratch of the separable blur+resize: group x H x (widest coarse layer)
+        float *I = nullptr, *R0 = nullptr, *R1 = nullptr, *Ma = nullptr, *Mb = nullptr, *fc[2] = {nullptr, nullptr};
+    } ws[2];
+    int nsets = 1;
+    bool pipeline = true;            // option "pipeline": overlap preparation of group i + 1 with the sweeps of group i
+    hipStream_t prep_stream = nullptr;
+    hipEvent_t prep_done[2] = {nullptr, nullptr}, fine_done[2] = {nullptr, nullptr}, call_begin = nullptr;
     size_t htmp_stride = 0;
-    float *I = nullptr, *R0 = nullptr, *R1 = nullptr, *Ma = nullptr, *Mb = nullptr, *fc[2] = {nullptr, nullptr};
     float* flow_ws = nullptr;      // lazily allocated (max_batch) when the caller does not want the flow
     // detection scratch (max_batch)
     FoeScratch foe_sc{nullptr, nullptr, nullptr};
@@ -221,14 +230,14 @@ struct mav_ctx {
 };
 
 struct ProfScope {
-    mav_ctx* c; int kid; hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(mav_ctx* c_, int k) : c(c_), kid(k)
+    mav_ctx* c; int kid; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(mav_ctx* c_, int k, hipStream_t st_ = nullptr) : c(c_), kid(k), st(st_ ? st_ : c_->stream)
     {
-        if (c->profiling) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, c->stream); }
+        if (c->profiling) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, st); }
     }
     ~ProfScope()
     {
-        if (c->profiling) { hipEventRecord(b, c->stream); c->prof.push_back({kid, a, b}); }
+        if (c->profiling) { hipEventRecord(b, st); c->prof.push_back({kid, a, b}); }
     }
 };
 
@@ -238,25 +247,32 @@ static void free_layer(Layer& l)
     l.g = nullptr;
 }
 
-// Workspace for `group` slots.  The new set is allocated in full before the old one is released: when an allocation fails the
-// context keeps its previous group and stays usable (the caller sees MAV_ERR_OOM).
+// Workspace for `group` slots (two sets when max_batch spans more than one group).  The new buffers are allocated in full
+// before the old ones are released: when an allocation fails the context keeps its previous group and stays usable (the caller
+// sees MAV_ERR_OOM).
 static int alloc_group(mav_ctx* c, int group)
 {
-    float** bufs[8] = {&c->I, &c->R0, &c->R1, &c->Ma, &c->Mb, &c->fc[0], &c->fc[1], &c->Htmp};
+    const int nsets = c->max_batch > group ? 2 : 1;
     const size_t g = (size_t)group, nc = 2 * (c->n1 ? c->n1 : 1);
     const size_t elems[8] = {c->n0 * g, 5 * c->n0 * g, 5 * c->n0 * g, 5 * c->n0 * g, 5 * c->n0 * g, nc * g, nc * g, c->htmp_stride * g};
-    float* fresh[8] = {nullptr};
-    for (int i = 0; i < 8; i++) {
-        const hipError_t e = hipMalloc(&fresh[i], sizeof(float) * elems[i]);
-        if (e != hipSuccess) {
-            for (int j = 0; j < i; j++) hipFree(fresh[j]);
-            (void)hipGetLastError();
-            return fail(e == hipErrorOutOfMemory ? MAV_ERR_OOM : MAV_ERR_HIP, "workspace for group %d (%zu bytes for buffer %d): %s", group,
-                        sizeof(float) * elems[i], i, hipGetErrorString(e));
+    float* fresh[2][8] = {{nullptr}, {nullptr}};
+    for (int s = 0; s < nsets; s++)
+        for (int i = 0; i < 8; i++) {
+            const hipError_t e = hipMalloc(&fresh[s][i], sizeof(float) * elems[i]);
+            if (e != hipSuccess) {
+                for (int t = 0; t <= s; t++) for (int j = 0; j < 8; j++) if (fresh[t][j]) hipFree(fresh[t][j]);
+                (void)hipGetLastError();
+                return fail(e == hipErrorOutOfMemory ? MAV_ERR_OOM : MAV_ERR_HIP, "workspace for group %d (%zu bytes for buffer %d of set %d): %s",
+                            group, sizeof(float) * elems[i], i, s, hipGetErrorString(e));
+            }
         }
+    for (int s = 0; s < 2; s++) {
+        mav_ctx::WorkSet& w = c->ws[s];
+        float** bufs[8] = {&w.I, &w.R0, &w.R1, &w.Ma, &w.Mb, &w.fc[0], &w.fc[1], &w.Htmp};
+        for (int i = 0; i < 8; i++) { if (*bufs[i]) hipFree(*bufs[i]); *bufs[i] = s < nsets ? fresh[s][i] : nullptr; }
     }
-    for (int i = 0; i < 8; i++) { if (*bufs[i]) hipFree(*bufs[i]); *bufs[i] = fresh[i]; }
     c->group = group;
+    c->nsets = nsets;
     return MAV_OK;
 }
 
@@ -266,7 +282,12 @@ extern "C" int mav_destroy(mav_ctx* c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto& l : c->layers) free_layer(l);
-    void* bufs[] = {c->I, c->R0, c->R1, c->Ma, c->Mb, c->fc[0], c->fc[1], c->Htmp, c->flow_ws, c->foe_sc.cand, c->foe_sc.count,
+    if (c->prep_stream) hipStreamSynchronize(c->prep_stream);
+    for (auto& w : c->ws) {
+        void* wb[] = {w.I, w.R0, w.R1, w.Ma, w.Mb, w.fc[0], w.fc[1], w.Htmp};
+        for (void* b : wb) if (b) hipFree(b);
+    }
+    void* bufs[] = {c->flow_ws, c->foe_sc.cand, c->foe_sc.count,
                     c->foe_sc.best_key, c->foe_dev, c->box_acc, c->u64_scratch, c->i32_scratch, c->derot_dev, c->pyr_ws, c->sat};
     for (void* b : bufs) if (b) hipFree(b);
     for (auto& blk : c->scratch) if (blk.p) hipFree(blk.p);
@@ -275,6 +296,8 @@ extern "C" int mav_destroy(mav_ctx* c)
     if (c->t1) hipEventDestroy(c->t1);
     if (c->copy_done) hipEventDestroy(c->copy_done);
     if (c->compute_mark) hipEventDestroy(c->compute_mark);
+    for (hipEvent_t e : {c->prep_done[0], c->prep_done[1], c->fine_done[0], c->fine_done[1], c->call_begin}) if (e) hipEventDestroy(e);
+    if (c->prep_stream) hipStreamDestroy(c->prep_stream);
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -315,6 +338,9 @@ extern "C" int mav_create(mav_ctx** out, int device, int W, int H, int max_batch
     HIPB(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     HIPB(hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming));
     HIPB(hipEventCreateWithFlags(&c->compute_mark, hipEventDisableTiming));
+    HIPB(hipStreamCreateWithFlags(&c->prep_stream, hipStreamNonBlocking));
+    for (hipEvent_t* e : {&c->prep_done[0], &c->prep_done[1], &c->fine_done[0], &c->fine_done[1], &c->call_begin})
+        HIPB(hipEventCreateWithFlags(e, hipEventDisableTiming));
     HIPB(hipEventCreate(&c->t0));
     HIPB(hipEventCreate(&c->t1));
     if (!prepare_poly(fb.poly_n, fb.poly_sigma, &c->pc)) { fail(MAV_ERR_ARG, "poly_sigma %g gives a singular moment matrix", fb.poly_sigma); return bail(MAV_ERR_ARG); }
@@ -352,6 +378,7 @@ extern "C" int mav_create(mav_ctx** out, int device, int W, int H, int max_batch
     if (const char* e = getenv("MAVFLOW_GROUP")) { int v = atoi(e); if (v >= 1) group = v < max_batch ? v : max_batch; }
     if (const char* e = getenv("MAVFLOW_RC")) c->use_rc = atoi(e) != 0;
     if (const char* e = getenv("MAVFLOW_GROUP_FINE")) { int v = atoi(e); if (v >= 0) c->group_fine = v; }
+    if (const char* e = getenv("MAVFLOW_PIPELINE")) c->pipeline = atoi(e) != 0;
     // the Infinity-Cache argument only holds while one pair's finest-layer working set (80 B/px) fits in it
     if ((size_t)W * H * 80 > (size_t)200 << 20) c->group_fine = 0;
     rc = alloc_group(c, group);
@@ -377,8 +404,10 @@ extern "C" int mav_set_option(mav_ctx* c, const char* name, long value)
         int g = value > c->max_batch ? c->max_batch : (int)value;
         HIPCHK(hipSetDevice(c->device));
         HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipStreamSynchronize(c->prep_stream));
         return g == c->group ? MAV_OK : alloc_group(c, g);
     }
+    if (!strcmp(name, "pipeline")) { c->pipeline = value != 0; return MAV_OK; }
     if (!strcmp(name, "recompute")) { c->use_rc = value != 0; return MAV_OK; }
     if (!strcmp(name, "group_fine")) {
         if (value < 0) return fail(MAV_ERR_ARG, "group_fine must be >= 0 (0 = same as group)");
@@ -526,84 +555,107 @@ static BlurParams blur_of(const mav_ctx* c, const Layer& l)
     return BlurParams{l.ksize, (l.ksize == 3 && l.sigma <= 0) ? 1 : 0, l.g, (double)c->W / l.w, (double)c->H / l.h};
 }
 
-static int farneback_group(mav_ctx* c, const uint8_t* prev, const uint8_t* next, int g, float* flow_out)
+// Initial M and the `iterations` sweeps of layer k for g slots of work set w, on stream st.  flow_prev = the coarser layer's
+// flow (pw x ph, nullptr at the top layer); the layer's flow goes to fdst (slot stride fstride).
+static void layer_sweeps(mav_ctx* c, mav_ctx::WorkSet& w, hipStream_t st, int k, int g, const float* flow_prev, size_t fc_stride, int pw,
+                         int ph, float* fdst, size_t fstride)
 {
     const size_t n0 = c->n0;
+    const Layer& l = c->layers[k];
+    const float mul = (float)(1. / c->fb.pyr_scale);
+    // The finest layer's ten sweeps re-read R0/R1 (and M or the flow): run them `group_fine` pairs at a time so that
+    // one sub-group's working set stays resident in the 256 MB Infinity Cache between sweeps.  Coarse layers are
+    // small: all g pairs per launch to fill the 256 CUs.
+    const int sub = (k == 0 && c->group_fine > 0 && c->group_fine < g) ? c->group_fine : g;
+    // Optional form ("recompute"): sweeps that rebuild M from (R0, R1, flow) on the fly -- no M arrays, no initial-M
+    // kernel, 56 instead of 80 B/px of HBM traffic; the flow ping-pongs between the (otherwise unused) Ma / Mb buffers.
+    // On MI355X at 1080p it is slower than the M-array form (27.6 vs 21.3 ms per 64 pairs: the limit is the per-CU
+    // request rate into L2, which the 2.08x halo recomputation raises), so it is off by default.
+    bool rc_ok = c->use_rc && c->fb.winsize / 2 == 6 && l.w % 4 == 0;
+    if (rc_ok) {
+        for (int s0 = 0; s0 < g && rc_ok; s0 += sub) {
+            const int gs = g - s0 < sub ? g - s0 : sub;
+            float* buf[2] = {w.Ma + (size_t)s0 * 5 * n0, w.Mb + (size_t)s0 * 5 * n0};
+            for (int it = 0; it < c->fb.iterations; it++) {
+                const bool last = it == c->fb.iterations - 1;
+                const int mode = it > 0 ? 2 : (flow_prev ? 1 : 0);
+                const float* fin = it > 0 ? buf[(it - 1) & 1] : (flow_prev ? flow_prev + (size_t)s0 * fc_stride : nullptr);
+                const size_t fin_stride = it > 0 ? 5 * n0 : fc_stride;
+                float* fo = last ? fdst + (size_t)s0 * fstride : buf[it & 1];
+                ProfScope ps(c, k == 0 ? K_ITER : K_ITER_COARSE, st);
+                if (!launch_sweep_rc(st, mode, fin, fin_stride, pw, ph, mul, w.R0 + (size_t)s0 * 5 * n0,
+                                     w.R1 + (size_t)s0 * 5 * n0, 5 * n0, gs, l.w, l.h, c->fb.winsize, fo, last ? fstride : 5 * n0)) {
+                    rc_ok = false;      // (only possible on the very first launch: alignment) -> M-array form below
+                    break;
+                }
+            }
+        }
+    }
+    if (rc_ok) return;
+    // with per-sub-group sweeps the initial M of a sub-group is built right before its sweeps: M, R0 and R1 are then
+    // still in the Infinity Cache when the first sweep reads them (measured -0.5 ms per 64 pairs; doing the same with the
+    // blur and the expansion costs more in small launches than it returns)
+    const bool m_per_sub = sub < g;
+    if (!m_per_sub) {
+        ProfScope ps(c, K_UPDATE, st);
+        launch_update_matrices(st, w.R0, w.R1, 5 * n0, flow_prev, fc_stride, pw, ph, mul, g, l.w, l.h, w.Ma, 5 * n0);
+    }
+    for (int s0 = 0; s0 < g; s0 += sub) {
+        const int gs = g - s0 < sub ? g - s0 : sub;
+        if (m_per_sub) {
+            ProfScope ps(c, K_UPDATE, st);
+            launch_update_matrices(st, w.R0 + (size_t)s0 * 5 * n0, w.R1 + (size_t)s0 * 5 * n0, 5 * n0,
+                                   flow_prev ? flow_prev + (size_t)s0 * fc_stride : nullptr, fc_stride, pw, ph, mul, gs, l.w, l.h,
+                                   w.Ma + (size_t)s0 * 5 * n0, 5 * n0);
+        }
+        float *Min = w.Ma + (size_t)s0 * 5 * n0, *Mout = w.Mb + (size_t)s0 * 5 * n0;
+        for (int it = 0; it < c->fb.iterations; it++) {
+            const int upd = it < c->fb.iterations - 1;
+            { ProfScope ps(c, k == 0 ? K_ITER : K_ITER_COARSE, st);
+              launch_blur_iter(st, Min, Mout, 5 * n0, w.R0 + (size_t)s0 * 5 * n0, w.R1 + (size_t)s0 * 5 * n0, 5 * n0, gs,
+                               l.w, l.h, c->fb.winsize, upd, !upd, fdst + (size_t)s0 * fstride, fstride); }
+            if (upd) { float* t = Min; Min = Mout; Mout = t; }
+        }
+    }
+}
+
+// Layer images and polynomial expansions of both frames at layer k (g slots of set w, stream st) -> w.R0, w.R1.
+static void layer_expansions(mav_ctx* c, mav_ctx::WorkSet& w, hipStream_t st, int k, const uint8_t* prev, const uint8_t* next, int g)
+{
+    const size_t n0 = c->n0;
+    const Layer& l = c->layers[k];
+    const uint8_t* img[2] = {prev, next};
+    float* R[2] = {w.R0, w.R1};
+    for (int i = 0; i < 2; i++) {
+        { ProfScope ps(c, K_BLUR_RESIZE, st);
+          launch_blur_resize(st, img[i], n0, g, c->W, c->H, l.w, l.h, blur_of(c, l), w.Htmp, c->htmp_stride, w.I, n0); }
+        { ProfScope ps(c, K_POLYEXP, st);
+          launch_polyexp(st, w.I, n0, g, l.w, l.h, c->pc, R[i], 5 * n0); }
+    }
+}
+
+// PREPARATION of a group: every coarse layer completely (top layer first), then the finest layer's images and expansions.
+// Leaves in w: R0 / R1 of layer 0 and, when there is a coarse layer, layer 1's flow in w.fc[1].
+static void prep_group(mav_ctx* c, mav_ctx::WorkSet& w, hipStream_t st, const uint8_t* prev, const uint8_t* next, int g)
+{
     const int L = (int)c->layers.size();
+    const size_t fc_stride = 2 * (c->n1 ? c->n1 : 1);
     const float* flow_prev = nullptr;
     int pw = 0, ph = 0;
-    const size_t fc_stride = 2 * (c->n1 ? c->n1 : 1);
-    for (int k = L - 1; k >= 0; k--) {
-        const Layer& l = c->layers[k];
-        const uint8_t* img[2] = {prev, next};
-        float* R[2] = {c->R0, c->R1};
-        // The finest layer's ten sweeps re-read R0/R1 (and M or the flow): run them `group_fine` pairs at a time so that
-        // one sub-group's working set stays resident in the 256 MB Infinity Cache between sweeps.  Coarse layers are
-        // small: all g pairs per launch to fill the 256 CUs.
-        const int sub = (k == 0 && c->group_fine > 0 && c->group_fine < g) ? c->group_fine : g;
-        for (int i = 0; i < 2; i++) {
-            { ProfScope ps(c, K_BLUR_RESIZE);
-              launch_blur_resize(c->stream, img[i], n0, g, c->W, c->H, l.w, l.h, blur_of(c, l), c->Htmp, c->htmp_stride, c->I, n0); }
-            { ProfScope ps(c, K_POLYEXP);
-              launch_polyexp(c->stream, c->I, n0, g, l.w, l.h, c->pc, R[i], 5 * n0); }
-        }
-        float* fdst = k > 0 ? c->fc[k & 1] : flow_out;
-        const size_t fstride = k > 0 ? fc_stride : 2 * n0;
-        const float mul = (float)(1. / c->fb.pyr_scale);
-        // Optional form ("recompute"): sweeps that rebuild M from (R0, R1, flow) on the fly -- no M arrays, no initial-M
-        // kernel, 56 instead of 80 B/px of HBM traffic; the flow ping-pongs between the (otherwise unused) Ma / Mb buffers.
-        // On MI355X at 1080p it is slower than the M-array form (27.6 vs 21.3 ms per 64 pairs: the limit is the per-CU
-        // request rate into L2, which the 2.08x halo recomputation raises), so it is off by default.
-        bool rc_ok = c->use_rc && c->fb.winsize / 2 == 6 && l.w % 4 == 0;
-        if (rc_ok) {
-            for (int s0 = 0; s0 < g && rc_ok; s0 += sub) {
-                const int gs = g - s0 < sub ? g - s0 : sub;
-                float* buf[2] = {c->Ma + (size_t)s0 * 5 * n0, c->Mb + (size_t)s0 * 5 * n0};
-                for (int it = 0; it < c->fb.iterations; it++) {
-                    const bool last = it == c->fb.iterations - 1;
-                    const int mode = it > 0 ? 2 : (flow_prev ? 1 : 0);
-                    const float* fin = it > 0 ? buf[(it - 1) & 1] : (flow_prev ? flow_prev + (size_t)s0 * fc_stride : nullptr);
-                    const size_t fin_stride = it > 0 ? 5 * n0 : fc_stride;
-                    float* fo = last ? fdst + (size_t)s0 * fstride : buf[it & 1];
-                    ProfScope ps(c, k == 0 ? K_ITER : K_ITER_COARSE);
-                    if (!launch_sweep_rc(c->stream, mode, fin, fin_stride, pw, ph, mul, c->R0 + (size_t)s0 * 5 * n0,
-                                         c->R1 + (size_t)s0 * 5 * n0, 5 * n0, gs, l.w, l.h, c->fb.winsize, fo, last ? fstride : 5 * n0)) {
-                        rc_ok = false;      // (only possible on the very first launch: alignment) -> M-array form below
-                        break;
-                    }
-                }
-            }
-        }
-        if (!rc_ok) {
-            // with per-sub-group sweeps the initial M of a sub-group is built right before its sweeps: M, R0 and R1 are then
-            // still in the Infinity Cache when the first sweep reads them (measured -0.5 ms per 64 pairs; doing the same with the
-            // blur and the expansion costs more in small launches than it returns)
-            const bool m_per_sub = sub < g;
-            if (!m_per_sub) {
-                ProfScope ps(c, K_UPDATE);
-                launch_update_matrices(c->stream, c->R0, c->R1, 5 * n0, flow_prev, fc_stride, pw, ph, mul, g, l.w, l.h, c->Ma, 5 * n0);
-            }
-            for (int s0 = 0; s0 < g; s0 += sub) {
-                const int gs = g - s0 < sub ? g - s0 : sub;
-                if (m_per_sub) {
-                    ProfScope ps(c, K_UPDATE);
-                    launch_update_matrices(c->stream, c->R0 + (size_t)s0 * 5 * n0, c->R1 + (size_t)s0 * 5 * n0, 5 * n0,
-                                           flow_prev ? flow_prev + (size_t)s0 * fc_stride : nullptr, fc_stride, pw, ph, mul, gs, l.w, l.h,
-                                           c->Ma + (size_t)s0 * 5 * n0, 5 * n0);
-                }
-                float *Min = c->Ma + (size_t)s0 * 5 * n0, *Mout = c->Mb + (size_t)s0 * 5 * n0;
-                for (int it = 0; it < c->fb.iterations; it++) {
-                    const int upd = it < c->fb.iterations - 1;
-                    { ProfScope ps(c, k == 0 ? K_ITER : K_ITER_COARSE);
-                      launch_blur_iter(c->stream, Min, Mout, 5 * n0, c->R0 + (size_t)s0 * 5 * n0, c->R1 + (size_t)s0 * 5 * n0, 5 * n0, gs,
-                                       l.w, l.h, c->fb.winsize, upd, !upd, fdst + (size_t)s0 * fstride, fstride); }
-                    if (upd) { float* t = Min; Min = Mout; Mout = t; }
-                }
-            }
-        }
-        flow_prev = fdst; pw = l.w; ph = l.h;
+    for (int k = L - 1; k >= 1; k--) {
+        layer_expansions(c, w, st, k, prev, next, g);
+        layer_sweeps(c, w, st, k, g, flow_prev, fc_stride, pw, ph, w.fc[k & 1], fc_stride);
+        flow_prev = w.fc[k & 1]; pw = c->layers[k].w; ph = c->layers[k].h;
     }
-    return check_launch("farneback kernels");
+    layer_expansions(c, w, st, 0, prev, next, g);
+}
+// SWEEPS of a group: the finest layer's initial M and iterations -> flow_out.
+static void fine_group(mav_ctx* c, mav_ctx::WorkSet& w, hipStream_t st, int g, float* flow_out)
+{
+    const int L = (int)c->layers.size();
+    const size_t fc_stride = 2 * (c->n1 ? c->n1 : 1);
+    layer_sweeps(c, w, st, 0, g, L > 1 ? w.fc[1] : nullptr, fc_stride, L > 1 ? c->layers[1].w : 0, L > 1 ? c->layers[1].h : 0,
+                 flow_out, 2 * c->n0);
 }
 
 extern "C" int mav_farneback_dev(mav_ctx* c, const uint8_t* prev, const uint8_t* next, int batch, float* flow)
@@ -611,9 +663,32 @@ extern "C" int mav_farneback_dev(mav_ctx* c, const uint8_t* prev, const uint8_t*
     if (!c || !prev || !next || !flow) return fail(MAV_ERR_ARG, "mav_farneback: NULL argument");
     if (batch < 1 || batch > c->max_batch) return fail(MAV_ERR_ARG, "batch %d outside [1, %d]", batch, c->max_batch);
     HIPCHK(hipSetDevice(c->device));
-    for (int g0 = 0; g0 < batch; g0 += c->group) {
+    // Two streams, two work sets: the finest layer's sweeps (75 % of the time; one pair per launch, bound by the latency of a
+    // tile and by the Infinity Cache) of group i run on the compute stream while group i + 1 is prepared on the preparation
+    // stream -- its kernels fill the slots the sweeps' second, partial round of workgroups leaves idle.  Events order the two:
+    // a set is prepared only after the sweeps that last used it (fine_done), swept only after its preparation (prep_done), and
+    // the preparation stream starts behind everything already enqueued on the compute stream (call_begin).  Per-kernel
+    // profiling runs everything on the compute stream so that each launch is timed alone.
+    const bool pipe = c->pipeline && c->nsets == 2 && batch > c->group && !c->profiling;
+    if (pipe) {
+        HIPCHK(hipEventRecord(c->call_begin, c->stream));
+        HIPCHK(hipStreamWaitEvent(c->prep_stream, c->call_begin, 0));
+    }
+    int gi = 0;
+    for (int g0 = 0; g0 < batch; g0 += c->group, gi++) {
         const int g = batch - g0 < c->group ? batch - g0 : c->group;
-        CHK(farneback_group(c, prev + (size_t)g0 * c->n0, next + (size_t)g0 * c->n0, g, flow + (size_t)g0 * 2 * c->n0));
+        const int set = pipe ? (gi & 1) : 0;
+        mav_ctx::WorkSet& w = c->ws[set];
+        const hipStream_t ps = pipe ? c->prep_stream : c->stream;
+        if (pipe && gi >= 2) HIPCHK(hipStreamWaitEvent(ps, c->fine_done[set], 0));
+        prep_group(c, w, ps, prev + (size_t)g0 * c->n0, next + (size_t)g0 * c->n0, g);
+        if (pipe) {
+            HIPCHK(hipEventRecord(c->prep_done[set], ps));
+            HIPCHK(hipStreamWaitEvent(c->stream, c->prep_done[set], 0));
+        }
+        fine_group(c, w, c->stream, g, flow + (size_t)g0 * 2 * c->n0);
+        if (pipe) HIPCHK(hipEventRecord(c->fine_done[set], c->stream));
+        CHK(check_launch("farneback kernels"));
     }
     c->last_flow = flow;
     return MAV_OK;
@@ -1207,7 +1282,7 @@ extern "C" int mav_stage_blur_resize(mav_ctx* c, const uint8_t* img, int k, floa
     const size_t n = (size_t)l->w * l->h;
     DevBuf di, dout;
     CHK(di.upload(c, img, c->n0)); CHK(dout.alloc(c, n * sizeof(float)));
-    launch_blur_resize(c->stream, di.as<uint8_t>(), c->n0, 1, c->W, c->H, l->w, l->h, blur_of(c, *l), c->Htmp, c->htmp_stride,
+    launch_blur_resize(c->stream, di.as<uint8_t>(), c->n0, 1, c->W, c->H, l->w, l->h, blur_of(c, *l), c->ws[0].Htmp, c->htmp_stride,
                        dout.as<float>(), n);
     CHK(check_launch("blur_resize"));
     CHK(download(c, out, dout.p, n * sizeof(float)));
