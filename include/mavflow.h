@@ -75,7 +75,8 @@ const char* mav_last_error(void); /* thread-local, never NULL */
 int mav_device_count(void);       /* <= 0 when no GPU is visible */
 /* Tuning: "group" = pairs per launch (>= 1, default 8); "group_fine" = pairs per launch for the finest layer's sweeps
  * (default 1: one pair's working set stays in the Infinity Cache; 0 = same as group); "recompute" = 1: sweeps rebuild M
- * from (R0, R1, flow) on the fly instead of storing it (default 0). MAV_ERR_ARG for unknown names. */
+ * from (R0, R1, flow) on the fly instead of storing it (default 0); "pipeline" = 1: a second work set and stream prepare
+ * group i + 1 (pyramid, expansions) while group i's finest-layer sweeps run (default 0: measured slower). MAV_ERR_ARG for unknown names. */
 int mav_set_option(mav_ctx*, const char* name, long value);
 int mav_num_layers(const mav_ctx*);
 int mav_layer_dims(const mav_ctx*, int k, int* w, int* h, int* ksize, double* sigma);
@@ -179,7 +180,7 @@ int mav_memcpy_d2h(mav_ctx*, void* dst, const void* src, size_t bytes);
  * enqueued on the context's stream AFTER the fence wait for the copies issued BEFORE it.  Double-buffered batches:
  *   upload_async(set B) ; process_batch_dev(set A) ; upload_fence() ; upload_async(set A) ; process_batch_dev(set B) ; ... */
 int mav_host_alloc(mav_ctx*, size_t bytes, void** out);
-int mav_host_free(mav_ctx*, void* p);
+int mav_host_free(mav_ctx* /* may be NULL: the memory may outlive its context */, void* p);
 int mav_upload_async(mav_ctx*, void* dst_dev, const void* src_host, size_t bytes);
 int mav_upload_fence(mav_ctx*);
 

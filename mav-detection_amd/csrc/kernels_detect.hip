@@ -297,7 +297,7 @@ static __device__ __forceinline__ bool phi_pixel_screen(float uf, float vf, int 
         const float prod2 = m2 * dd;
         const float dot = uf * dxf + vf * dyf;
         const float crs = fabsf(uf * dyf - vf * dxf);
-        const float S = sqrtf(prod2);
+        const float S = __builtin_amdgcn_sqrtf(prod2);           // raw v_sqrt_f32 (1 ulp): S only scales the margins
         bool sure = prod2 > 1e-8f && prod2 < 1e30f;       // norm floor (1e-6) and inf/NaN stay on the exact path
         const bool gate_f = m2 > scr.fmm2, gate_d = m2 > scr.dmm2;
         sure = sure && fabsf(m2 - scr.fmm2) > 1e-5f * scr.fmm2 && fabsf(m2 - scr.dmm2) > 1e-5f * scr.dmm2;
@@ -308,13 +308,13 @@ static __device__ __forceinline__ bool phi_pixel_screen(float uf, float vf, int 
                 sure = sure && fabsf(r) > MAV_SCREEN_TAN_MARGIN * S * (1.f + scr.tan_fixed);
                 f = r > 0.f;
             } else {
-                const float arg = dot * rsqrtf(prod2);
+                const float arg = dot * __builtin_amdgcn_rsqf(prod2);
                 sure = sure && fabsf(arg - scr.cos_fixed) > 2e-5f;
                 f = arg < scr.cos_fixed;
             }
         }
         if (gate_d && notsky) {
-            const float T = scr.dyn_ab + scr.dyn_c * rsqrtf(m2);  // degrees, >= 0
+            const float T = scr.dyn_ab + scr.dyn_c * __builtin_amdgcn_rsqf(m2);  // degrees, >= 0; raw v_rsq_f32 (1 ulp, in the error budget)
             if (T < MAV_SCREEN_TAN_MAX_DEG) {
                 const float x = T * 0.017453292519943295f, x2 = x * x;
                 const float tT = x * (1.f + x2 * (0.33333333333f + x2 * (0.13333333333f + x2 * (0.05396825397f + x2 * 0.02186948854f))));
@@ -322,7 +322,7 @@ static __device__ __forceinline__ bool phi_pixel_screen(float uf, float vf, int 
                 sure = sure && fabsf(r) > MAV_SCREEN_TAN_MARGIN * S * (1.f + tT);
                 d = r > 0.f;
             } else if (T < 179.f) {
-                const float arg = dot * rsqrtf(prod2);
+                const float arg = dot * __builtin_amdgcn_rsqf(prod2);
                 const float cT = __cosf(T * 0.017453292519943295f);
                 sure = sure && fabsf(arg - cT) > 1e-4f;
                 d = arg < cT;

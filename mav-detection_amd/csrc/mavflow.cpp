@@ -201,7 +201,7 @@ struct mav_ctx {
         float *I = nullptr, *R0 = nullptr, *R1 = nullptr, *Ma = nullptr, *Mb = nullptr, *fc[2] = {nullptr, nullptr};
     } ws[2];
     int nsets = 1;
-    bool pipeline = true;            // option "pipeline": overlap preparation of group i + 1 with the sweeps of group i
+    bool pipeline = false;           // option "pipeline" (off: measured 2 % slower): prepare group i + 1 while group i sweeps
     hipStream_t prep_stream = nullptr;
     hipEvent_t prep_done[2] = {nullptr, nullptr}, fine_done[2] = {nullptr, nullptr}, call_begin = nullptr;
     size_t htmp_stride = 0;
@@ -252,7 +252,7 @@ static void free_layer(Layer& l)
 // sees MAV_ERR_OOM).
 static int alloc_group(mav_ctx* c, int group)
 {
-    const int nsets = c->max_batch > group ? 2 : 1;
+    const int nsets = (c->pipeline && c->max_batch > group) ? 2 : 1;
     const size_t g = (size_t)group, nc = 2 * (c->n1 ? c->n1 : 1);
     const size_t elems[8] = {c->n0 * g, 5 * c->n0 * g, 5 * c->n0 * g, 5 * c->n0 * g, 5 * c->n0 * g, nc * g, nc * g, c->htmp_stride * g};
     float* fresh[2][8] = {{nullptr}, {nullptr}};
@@ -407,7 +407,17 @@ extern "C" int mav_set_option(mav_ctx* c, const char* name, long value)
         HIPCHK(hipStreamSynchronize(c->prep_stream));
         return g == c->group ? MAV_OK : alloc_group(c, g);
     }
-    if (!strcmp(name, "pipeline")) { c->pipeline = value != 0; return MAV_OK; }
+    if (!strcmp(name, "pipeline")) {      // the second work set exists only while the option is on
+        const bool on = value != 0;
+        if (on == c->pipeline) return MAV_OK;
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipStreamSynchronize(c->prep_stream));
+        c->pipeline = on;
+        const int rc = alloc_group(c, c->group);
+        if (rc != MAV_OK) c->pipeline = !on;
+        return rc;
+    }
     if (!strcmp(name, "recompute")) { c->use_rc = value != 0; return MAV_OK; }
     if (!strcmp(name, "group_fine")) {
         if (value < 0) return fail(MAV_ERR_ARG, "group_fine must be >= 0 (0 = same as group)");
@@ -471,7 +481,7 @@ extern "C" int mav_host_alloc(mav_ctx* c, size_t bytes, void** out)
 }
 extern "C" int mav_host_free(mav_ctx* c, void* p)
 {
-    if (!c) return fail(MAV_ERR_ARG, "mav_host_free: NULL context");
+    (void)c;                     // page-locked memory outlives the context that allocated it (NULL context allowed)
     if (p) HIPCHK(hipHostFree(p));
     return MAV_OK;
 }
@@ -663,9 +673,12 @@ extern "C" int mav_farneback_dev(mav_ctx* c, const uint8_t* prev, const uint8_t*
     if (!c || !prev || !next || !flow) return fail(MAV_ERR_ARG, "mav_farneback: NULL argument");
     if (batch < 1 || batch > c->max_batch) return fail(MAV_ERR_ARG, "batch %d outside [1, %d]", batch, c->max_batch);
     HIPCHK(hipSetDevice(c->device));
-    // Two streams, two work sets: the finest layer's sweeps (75 % of the time; one pair per launch, bound by the latency of a
-    // tile and by the Infinity Cache) of group i run on the compute stream while group i + 1 is prepared on the preparation
-    // stream -- its kernels fill the slots the sweeps' second, partial round of workgroups leaves idle.  Events order the two:
+    // Option "pipeline" (off by default): two streams, two work sets -- the finest layer's sweeps (75 % of the time; one pair per
+    // launch, bound by the latency of a tile and by the Infinity Cache) of group i run on the compute stream while group i + 1
+    // is prepared on the preparation stream, its kernels filling the slots the sweeps' second, partial round of workgroups
+    // leaves idle.  Measured on MI355X: 29.1 vs 28.5 ms per 64 pairs at 1080p, 34.1 vs 33.3 ms per 16 pairs at 4K -- the
+    // preparation's HBM streams evict part of the sweeping pair's working set from the Infinity Cache and cost the sweeps more
+    // than the filled slots return.  Kept switchable (parity-green either way).  Events order the two streams:
     // a set is prepared only after the sweeps that last used it (fine_done), swept only after its preparation (prep_done), and
     // the preparation stream starts behind everything already enqueued on the compute stream (call_begin).  Per-kernel
     // profiling runs everything on the compute stream so that each launch is timed alone.
