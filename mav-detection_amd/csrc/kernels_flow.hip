@@ -740,17 +740,12 @@ static __device__ __forceinline__ void update_finish(const float q[5], const Gat
 struct __attribute__((packed, aligned(4))) F2U { float x, y; };     // two adjacent floats at 4-byte alignment
 // AL = true: width a multiple of 4 and 16-byte aligned planes (vector loads / stores as written); AL = false: any width -- the
 // column pairs are read as two floats at 4-byte alignment and the flow is stored pixel by pixel.
-// XP = true (needs AL): R0 comes in and M' goes out as float4 rows per lane (5 + 5 vector-memory instructions per thread instead
-// of 20 + 20 dword ones) and is transposed to / from the lane = column layout of phase C through the wave's own LDS rows, which
-// are free once phase B has read them.  The kernel issues ~100 vector-memory instructions per wave and its waves spend half
-// their life stalled at issue: fewer, wider accesses for everything that is not a gather.
-template <int M_T, bool AL = true, bool XP = false>
-__global__ __launch_bounds__(256, 5) void k_blur_iter_fast(const float* __restrict__ M_in, float* __restrict__ M_out,
+template <int M_T, bool AL = true>
+__global__ __launch_bounds__(256) void k_blur_iter_fast(const float* __restrict__ M_in, float* __restrict__ M_out,
                                                         size_t M_stride, const float* __restrict__ R0,
                                                         const float* __restrict__ R1, size_t R_stride, int w, int h,
                                                         TileMap tm, float scale,
-                                                        int do_update, int store_flow, float* __restrict__ flow, size_t f_stride,
-                                                        int stagger)
+                                                        int do_update, int store_flow, float* __restrict__ flow, size_t f_stride)
 {
     constexpr int EXT_X = FT_X + 2 * M_T;              // 76
     constexpr int EXT_Y = FT_Y + 2 * M_T;              // 28
@@ -763,10 +758,6 @@ __global__ __launch_bounds__(256, 5) void k_blur_iter_fast(const float* __restri
     const int lane = tid & 63, wv = tid >> 6;
     int s, tx, ty;                                       // XCD-aware tile order, see tile_of_block()
     if (!tile_of_block(tm, &s, &tx, &ty)) return;
-    // EXPERIMENT (MAVFLOW_STAGGER): all workgroups of the first residency round start together and run their memory and
-    // arithmetic phases in lockstep; delaying every other resident slot of a CU by part of a tile time interleaves them.
-    if (stagger > 0 && blockIdx.x < 1280u && ((blockIdx.x >> 8) & 1u))
-        for (int i = 0; i < stagger; i++) __builtin_amdgcn_s_sleep(32);
     const int x0 = tx * FT_X, y0 = ty * FT_Y;
     const size_t npx = (size_t)w * h;
     const float* Min = M_in + (size_t)s * M_stride;
@@ -774,22 +765,17 @@ __global__ __launch_bounds__(256, 5) void k_blur_iter_fast(const float* __restri
     const float* R1p = R1 + (size_t)s * R_stride;
 
     STAMP(ts0);
-    // entry: R0 of this thread's four phase-C pixels (rows 4*wv + j, column lane) -- or, XP, of its four phase-B pixels as one
-    // float4 per plane (transposed into the phase-C layout through LDS later)
+    // entry: R0 of this thread's four phase-C pixels (rows 4*wv + j, column lane)
     float q[4][5];
-    float r0v[5][4];
     int gys[4];
     const int gxc = min(x0 + lane, w - 1);
     if (do_update) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) gys[j] = min(y0 + wv * 4 + j, h - 1);
-        if constexpr (!XP) {
+        for (int j = 0; j < 4; j++) {
+            gys[j] = min(y0 + wv * 4 + j, h - 1);
+            const size_t idx = (size_t)gys[j] * w + gxc;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const size_t idx = (size_t)gys[j] * w + gxc;
-#pragma unroll
-                for (int c = 0; c < 5; c++) q[j][c] = R0p[c * npx + idx];
-            }
+            for (int c = 0; c < 5; c++) q[j][c] = R0p[c * npx + idx];
         }
     }
 
@@ -837,33 +823,18 @@ __global__ __launch_bounds__(256, 5) void k_blur_iter_fast(const float* __restri
             }
         }
     }
-    // phase-B lane mapping = the hardware's ds_read_b128 lane groups (quads of 4 lanes: g0 = quads {0,3,5,6}, g1 = quads
-    // {1,2,4,7}, +2 for lanes 32..63): lane -> tile row wv * 4 + grp, four consecutive pixels from column pos * 4
-    // (computed after phase A: four fewer registers live across its 56 load registers)
-    const int quad = (lane & 31) >> 2;
-    const int grp = (lane >> 5) * 2 + ((quad == 1 || quad == 2 || quad == 4 || quad == 7) ? 1 : 0);
-    const int qpos = (quad == 0 || quad == 1) ? 0 : ((quad == 3 || quad == 2) ? 1 : ((quad == 5 || quad == 4) ? 2 : 3));
-    const int pos = qpos * 4 + (lane & 3);          // 0..15 inside the group
-    if constexpr (XP) {
-        // R0 is requested here, once phase A's 56 load registers are dead (at kernel entry it would push the kernel over the
-        // 96-register step to 4 waves per SIMD): the barrier and phase B cover its latency
-        if (do_update) {
-            const size_t idx = (size_t)min(y0 + wv * 4 + grp, h - 1) * w + min(x0 + pos * 4, w - 4);
-#pragma unroll
-            for (int c = 0; c < 5; c++) {
-                const float4 t4 = *(const float4*)(R0p + c * npx + idx);
-                r0v[c][0] = t4.x; r0v[c][1] = t4.y; r0v[c][2] = t4.z; r0v[c][3] = t4.w;
-            }
-        }
-    }
     STAMP(ts1);
     __syncthreads();
     STAMP(ts2);
 
-    const int bly = wv * 4 + grp, blx0 = pos * 4;       // this lane's tile row and first column in phase B
     {
-        const int ly = bly;                              // tile row 0..15
-        const int lx0 = blx0;
+        // hardware b128 lane group (quads of 4 lanes: g0 = quads {0,3,5,6}, g1 = quads {1,2,4,7}, +2 for lanes 32..63)
+        const int quad = (lane & 31) >> 2;
+        const int grp = (lane >> 5) * 2 + ((quad == 1 || quad == 2 || quad == 4 || quad == 7) ? 1 : 0);
+        const int qpos = (quad == 0 || quad == 1) ? 0 : ((quad == 3 || quad == 2) ? 1 : ((quad == 5 || quad == 4) ? 2 : 3));
+        const int pos = qpos * 4 + (lane & 3);          // 0..15 inside the group
+        const int ly = wv * 4 + grp;                     // tile row 0..15
+        const int lx0 = pos * 4;
         const int gx = x0 + lx0, gy = y0 + ly;
         float S[5][4];
 #pragma unroll
@@ -902,23 +873,6 @@ __global__ __launch_bounds__(256, 5) void k_blur_iter_fast(const float* __restri
             }
         }
         if (!do_update) return;
-        if constexpr (XP) {
-            // R0: float4 rows (phase-B layout) -> this wave's own LDS rows -> one value per (row, column = lane).  Every read
-            // of those rows by this wave (phase B) is older in program order, and no other wave touches them.
-#pragma unroll
-            for (int c = 0; c < 5; c++)
-                *(float4*)(vs + c * PLANE + ly * PITCH + lx0) = make_float4(r0v[c][0], r0v[c][1], r0v[c][2], r0v[c][3]);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-#pragma unroll
-                for (int c = 0; c < 5; c++) q[j][c] = vs[c * PLANE + (wv * 4 + j) * PITCH + lane];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
         // park the flow in this wave's own rows of planes 0 (u) and 1 (v); every read of those rows by this wave is
         // older in program order, and no other wave touches them
         *(float4*)(vs + ly * PITCH + lx0) = make_float4(u[0], u[1], u[2], u[3]);
@@ -946,12 +900,7 @@ __global__ __launch_bounds__(256, 5) void k_blur_iter_fast(const float* __restri
         for (int jj = 0; jj < 2; jj++) {
             float o[5];
             update_finish(q[jb + jj], g[jj], w, h, gxc, gys[jb + jj], fu[jj], fv[jj], o);
-            if constexpr (XP) {
-                // M' of (row, column = lane) into the wave's LDS rows: this lane has already taken the flow of that very
-                // position out of planes 0 / 1, and the other rows' flow sits in other rows
-#pragma unroll
-                for (int c = 0; c < 5; c++) vs[c * PLANE + (wv * 4 + jb + jj) * PITCH + lane] = o[c];
-            } else if (colok && y0 + wv * 4 + jb + jj < h) {
+            if (colok && y0 + wv * 4 + jb + jj < h) {
                 const size_t idx = (size_t)gys[jb + jj] * w + gxc;
 #pragma unroll
                 for (int c = 0; c < 5; c++) Mo[c * npx + idx] = o[c];
@@ -960,16 +909,6 @@ __global__ __launch_bounds__(256, 5) void k_blur_iter_fast(const float* __restri
 #ifdef MAV_STAMPS
         if (jb == 0) { STAMP(tsm); STAMP_ADD(3, ts3, tsm); STAMP_ADD(5, tsm, tsm); }
 #endif
-    }
-    if constexpr (XP) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (x0 + blx0 < w && y0 + bly < h) {              // w % 4 == 0: the four pixels are all inside or all outside
-            const size_t idx = (size_t)(y0 + bly) * w + x0 + blx0;
-#pragma unroll
-            for (int c = 0; c < 5; c++) *(float4*)(Mo + c * npx + idx) = *(const float4*)(vs + c * PLANE + bly * PITCH + blx0);
-        }
     }
     STAMP(ts4);
     STAMP_ADD(0, ts0, ts1); STAMP_ADD(1, ts1, ts2); STAMP_ADD(2, ts2, ts3); STAMP_ADD(4, ts3, ts4); STAMP_ADD(6, ts0, ts4); STAMP_ADD(7, 0ull, 1ull);
@@ -1130,21 +1069,14 @@ void launch_blur_iter(hipStream_t st, const float* M_in, float* M_out, size_t M_
                         aligned16(M_out) && aligned16(R0) && aligned16(R1) && aligned16(flow);
     if (m == 6 && vec_ok) {
         const TileMap tm = make_tile_map(w, h, G, FT_X, FT_Y);
-        static int stagger = -1, xp = -1;
-        if (stagger < 0) { const char* e = getenv("MAVFLOW_STAGGER"); stagger = e ? atoi(e) : 0; }
-        if (xp < 0) { const char* e = getenv("MAVFLOW_SWEEP_XP"); xp = e ? atoi(e) : 1; }
-        if (xp && w >= 4)
-            hipLaunchKernelGGL((k_blur_iter_fast<6, true, true>), dim3(tile_grid(tm)), dim3(256), 0, st, M_in, M_out, M_stride, R0, R1,
-                               R_stride, w, h, tm, scale, do_update, store_flow, flow, f_stride, stagger);
-        else
-            hipLaunchKernelGGL((k_blur_iter_fast<6, true, false>), dim3(tile_grid(tm)), dim3(256), 0, st, M_in, M_out, M_stride, R0, R1,
-                               R_stride, w, h, tm, scale, do_update, store_flow, flow, f_stride, stagger);
+        hipLaunchKernelGGL(k_blur_iter_fast<6>, dim3(tile_grid(tm)), dim3(256), 0, st, M_in, M_out, M_stride, R0, R1, R_stride, w, h,
+                           tm, scale, do_update, store_flow, flow, f_stride);
         return;
     }
     if (m == 6 && f_stride % 2 == 0 && ((uintptr_t)flow & 7) == 0) {    // any width / alignment: relaxed form of the same kernel
         const TileMap tm = make_tile_map(w, h, G, FT_X, FT_Y);
-        hipLaunchKernelGGL((k_blur_iter_fast<6, false, false>), dim3(tile_grid(tm)), dim3(256), 0, st, M_in, M_out, M_stride, R0, R1, R_stride,
-                           w, h, tm, scale, do_update, store_flow, flow, f_stride, 0);
+        hipLaunchKernelGGL((k_blur_iter_fast<6, false>), dim3(tile_grid(tm)), dim3(256), 0, st, M_in, M_out, M_stride, R0, R1, R_stride,
+                           w, h, tm, scale, do_update, store_flow, flow, f_stride);
         return;
     }
     iter_geometry(m, &ext, &pitch, &plane);

@@ -179,7 +179,7 @@ class _PinnedPool:
     """Page-locked host memory for the arrays the host-pointer entry points hand back.  A fresh numpy array is pageable and
     untouched: a 16.6 MB flow field costs ~4000 first-touch page faults plus the runtime's staging copy, more than the GPU
     needs to compute it.  Results are therefore written into page-locked blocks (PCIe rate, no faults) that return to this
-    pool when the numpy array that views them is garbage-collected (weakref.finalize on the array; views keep it alive).
+    pool when the last numpy array or view over them is garbage-collected.
     Module-level: a block lent out survives the context that allocated it."""
 
     def __init__(self):
@@ -196,9 +196,11 @@ class _PinnedPool:
             p = C.c_void_p()
             check(ctx.lib.mav_host_alloc(ctx.h, nbytes, C.byref(p)))
             ptr = p.value
-        arr = np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(ptr)).view(dtype)[:int(np.prod(shape))].reshape(shape)
-        weakref.finalize(arr, self._give, nbytes, ptr)
-        return arr
+        # the finalizer hangs on the ctypes object that OWNS the memory in numpy's eyes: every array or view derived from it
+        # (numpy collapses view chains onto the owner) keeps it alive, so the block returns only when the last of them is gone
+        owner = (C.c_uint8 * nbytes).from_address(ptr)
+        weakref.finalize(owner, self._give, nbytes, ptr)
+        return np.ctypeslib.as_array(owner).view(dtype)[:int(np.prod(shape))].reshape(shape)
 
     def _give(self, nbytes, ptr):
         lst = self.free.setdefault(nbytes, [])
