@@ -253,9 +253,8 @@ static __device__ __forceinline__ void wave_box_commit(int x0, int y0, int x1, i
 // Screening constants for the single-precision fast path (host-computed, see phi_screen()).
 struct PhiScreen {
     int enabled;         // 0: every pixel takes the exact double path
-    int fixed_tan;       // fixed_deg in (0, 80): the fixed threshold is screened in the tangent form
-    float cos_fixed;     // cos(fixed_deg)
-    float tan_fixed;     // tan(fixed_deg)
+    float tan_fixed;     // tan(fixed_deg), fixed_deg in (0, 80)
+    float margin_fixed;  // MAV_SCREEN_TAN_MARGIN * (1 + tan_fixed)
     float fmm2, dmm2;    // fixed_min_mag^2, dyn_min_mag^2
     float dyn_ab, dyn_c; // dyn_a + dyn_b, dyn_c
 };
@@ -277,61 +276,38 @@ static __device__ __forceinline__ double phi_exact(double u, double v, double d2
 }
 
 // Single-precision screen of one pixel of the phi / mask stage.  Returns true when both verdicts are certain (then *fix_out /
-// *dyn_out hold them); false sends the pixel to phi_pixel_exact().
-static __device__ __forceinline__ bool phi_pixel_screen(float uf, float vf, int x, int y, double foex, double foey, bool notsky,
-                                                        const PhiScreen& scr, bool* fix_out, bool* dyn_out)
+// *dyn_out hold them); false sends the pixel to phi_pixel_exact().  For a threshold T below 90 degrees
+//     phi > T   <=>   dot <= 0  or  |cross| > tan(T) * dot        (dot = f . d, cross = f x d, d = p - FoE),
+// and this form is well conditioned exactly where the thresholds live (a few degrees): in float32 dot and |cross| are each
+// within 4.2e-7 S of their exact values (S = |f| |d|), tan(T) within 6.5e-7 relative, so  r = |cross| - tan(T) dot  is within
+// 1.2e-6 S (1 + tan T) of its exact value and its sign is the exact path's verdict whenever |r| exceeds the 4e-6 margin: an
+// angular band of ~2e-4 degrees, ~1e-5 of the pixels.  (The arccos-argument form of round 1, arg < cos T with a 1e-4 band, is
+// ill conditioned at small T -- d arg = sin T dT -- and sent every pixel within ~0.15 degrees of a 2-degree threshold down the
+// double path.)  tan(T) of the dynamic threshold T = dyn_a + dyn_b + dyn_c / |f| comes from the degree-9 series, good to 5e-8
+// relative up to 17 degrees (every |f| >= 0.5 with the reference's constants); larger dynamic thresholds go to the exact path.
+// Magnitude gates: 1e-5 relative around both.  Branch-free, explicit FMAs (this file is built with -ffp-contract=off): the
+// kernel is instruction-bound (PMC: 10 % of its cycles waiting on memory), so every instruction here is paid 133 M times a step.
+static __device__ __forceinline__ bool phi_pixel_screen(float uf, float vf, float dxf, float dyf, bool notsky, const PhiScreen& scr,
+                                                        bool* fix_out, bool* dyn_out)
 {
-    const double d2x = (double)x - foex, d2y = (double)y - foey;
-    {
-        // Single-precision screen.  For a threshold T below 90 degrees
-        //     phi > T   <=>   dot <= 0  or  |cross| > tan(T) * dot        (dot = f . d, cross = f x d, d = p - FoE),
-        // and this form is well conditioned exactly where the thresholds live (a few degrees): in float32 dot and |cross| are
-        // each within 4.2e-7 S of their exact values (S = |f| |d|), tan(T) within 6.5e-7 relative, so  r = |cross| - tan(T) dot
-        // is within 1.2e-6 S (1 + tan T) of its exact value and its sign is the exact path's verdict whenever |r| exceeds the
-        // 4e-6 margin: an angular band of ~2e-4 degrees, ~1e-5 of the pixels.  (The arccos-argument form used before, arg < cos T
-        // with a 1e-4 band, is ill conditioned at small T -- d arg = sin T dT -- and sent every pixel within ~0.15 degrees of a
-        // 2-degree threshold down the double path: most waves of a real flow field.)  The cosine form remains for dynamic
-        // thresholds above 17 degrees (|flow| < 0.5, reachable only with non-default gates).  Gates: 1e-5 relative around both.
-        const float dxf = (float)d2x, dyf = (float)d2y;
-        const float m2 = uf * uf + vf * vf, dd = dxf * dxf + dyf * dyf;
-        const float prod2 = m2 * dd;
-        const float dot = uf * dxf + vf * dyf;
-        const float crs = fabsf(uf * dyf - vf * dxf);
-        const float S = __builtin_amdgcn_sqrtf(prod2);           // raw v_sqrt_f32 (1 ulp): S only scales the margins
-        bool sure = prod2 > 1e-8f && prod2 < 1e30f;       // norm floor (1e-6) and inf/NaN stay on the exact path
-        const bool gate_f = m2 > scr.fmm2, gate_d = m2 > scr.dmm2;
-        sure = sure && fabsf(m2 - scr.fmm2) > 1e-5f * scr.fmm2 && fabsf(m2 - scr.dmm2) > 1e-5f * scr.dmm2;
-        bool f = false, d = false;
-        if (gate_f && notsky) {
-            if (scr.fixed_tan) {
-                const float r = crs - scr.tan_fixed * dot;
-                sure = sure && fabsf(r) > MAV_SCREEN_TAN_MARGIN * S * (1.f + scr.tan_fixed);
-                f = r > 0.f;
-            } else {
-                const float arg = dot * __builtin_amdgcn_rsqf(prod2);
-                sure = sure && fabsf(arg - scr.cos_fixed) > 2e-5f;
-                f = arg < scr.cos_fixed;
-            }
-        }
-        if (gate_d && notsky) {
-            const float T = scr.dyn_ab + scr.dyn_c * __builtin_amdgcn_rsqf(m2);  // degrees, >= 0; raw v_rsq_f32 (1 ulp, in the error budget)
-            if (T < MAV_SCREEN_TAN_MAX_DEG) {
-                const float x = T * 0.017453292519943295f, x2 = x * x;
-                const float tT = x * (1.f + x2 * (0.33333333333f + x2 * (0.13333333333f + x2 * (0.05396825397f + x2 * 0.02186948854f))));
-                const float r = crs - tT * dot;
-                sure = sure && fabsf(r) > MAV_SCREEN_TAN_MARGIN * S * (1.f + tT);
-                d = r > 0.f;
-            } else if (T < 179.f) {
-                const float arg = dot * __builtin_amdgcn_rsqf(prod2);
-                const float cT = __cosf(T * 0.017453292519943295f);
-                sure = sure && fabsf(arg - cT) > 1e-4f;
-                d = arg < cT;
-            } else
-                sure = sure && T > 181.f;                         // phi <= 180 < T: certainly false
-        }
-        *fix_out = f; *dyn_out = d;
-        return sure;
-    }
+    const float m2 = fmaf(uf, uf, vf * vf), dd = fmaf(dxf, dxf, dyf * dyf);
+    const float prod2 = m2 * dd;
+    const float dot = fmaf(uf, dxf, vf * dyf);
+    const float crs = fabsf(fmaf(uf, dyf, -(vf * dxf)));
+    const float S = __builtin_amdgcn_sqrtf(prod2);            // raw v_sqrt_f32 (1 ulp): S only scales the margins
+    // norm floor (1e-6), inf / NaN and the two magnitude gates' bands stay on the exact path
+    const bool ok = (int)(prod2 > 1e-8f) & (int)(prod2 < 1e30f) & (int)(fabsf(m2 - scr.fmm2) > 1e-5f * scr.fmm2) & (int)(fabsf(m2 - scr.dmm2) > 1e-5f * scr.dmm2);
+    const bool act_f = (m2 > scr.fmm2) & notsky, act_d = (m2 > scr.dmm2) & notsky;
+    const float rf = fmaf(-scr.tan_fixed, dot, crs);
+    const bool ok_f = fabsf(rf) > scr.margin_fixed * S;
+    const float T = fmaf(scr.dyn_c, __builtin_amdgcn_rsqf(m2), scr.dyn_ab);      // degrees, >= 0; raw v_rsq_f32 (1 ulp, in the budget)
+    const float x = T * 0.017453292519943295f, x2 = x * x;
+    const float tT = x * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 0.02186948854f, 0.05396825397f), 0.13333333333f), 0.33333333333f), 1.f);
+    const float rd = fmaf(-tT, dot, crs);
+    const bool ok_d = (T < MAV_SCREEN_TAN_MAX_DEG) & (fabsf(rd) > MAV_SCREEN_TAN_MARGIN * fmaf(S, tT, S));
+    *fix_out = act_f & (rf > 0.f);
+    *dyn_out = act_d & (rd > 0.f);
+    return ok & (!act_f | ok_f) & (!act_d | ok_d);
 }
 
 // The exact path of one pixel: double arithmetic in numpy's order (phi_exact) and the literal threshold block.  Out of line on
@@ -383,7 +359,8 @@ static __device__ __noinline__ PhiVerdict phi_pixel_f32(float u, float v, float 
 
 // VEC = 4: one thread = 4 consecutive pixels x 4 rows (W % 4 == 0): float4 / double2 row loads, uchar4 mask stores;
 // workgroup = 256 columns x 16 rows.  VEC = 1: any width, one pixel per lane and row, 4 rows per thread.
-template <typename FlowT, int VEC>
+// ROT = false: the launch carries no per-pair parameters (no rates, no frame-0 pair): pass 1 has no derotation code at all.
+template <typename FlowT, int VEC, bool ROT>
 __global__ __launch_bounds__(256) void k_phi_mask(const FlowT* __restrict__ flow, const DerotParams* __restrict__ derot,
                                                   const double* __restrict__ foe, const uint8_t* __restrict__ sky, int W, int H,
                                                   mav_thr_params thr, PhiScreen scr, double* __restrict__ phi_out,
@@ -394,8 +371,8 @@ __global__ __launch_bounds__(256) void k_phi_mask(const FlowT* __restrict__ flow
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const size_t npx = (size_t)W * H;
     const FlowT* fl = flow + b * npx * 2;
-    const DerotParams* dp = derot ? derot + b : nullptr;
-    const bool f32_pair = std::is_same<FlowT, float>::value && dp && dp->mode == MAV_PAIR_FRAME0;
+    const DerotParams* dp = (ROT && derot) ? derot + b : nullptr;
+    const bool f32_pair = ROT && std::is_same<FlowT, float>::value && dp && dp->mode == MAV_PAIR_FRAME0;
     const double foex = foe[2 * b], foey = foe[2 * b + 1];
     int bx0 = INT_MAX, by0 = INT_MAX, bx1 = -1, by1 = -1;
     double pmax = 0.0;
@@ -418,6 +395,11 @@ __global__ __launch_bounds__(256) void k_phi_mask(const FlowT* __restrict__ flow
     }
     unsigned fixb = 0u, dynb = 0u, todo = 0u;
     const bool screen = scr.enabled && !f32_pair;
+    float dxf[VEC], dyf[4];                               // p - FoE: formed in double as the exact path does, then rounded once
+#pragma unroll
+    for (int j = 0; j < VEC; j++) dxf[j] = (float)((double)(xb + j) - foex);
+#pragma unroll
+    for (int r = 0; r < 4; r++) dyf[r] = (float)((double)(yb + r) - foey);
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         if (yb + r >= H || !colok) continue;
@@ -427,12 +409,18 @@ __global__ __launch_bounds__(256) void k_phi_mask(const FlowT* __restrict__ flow
             const bool notsky = ((skw[r] >> (8 * j)) & 255u) == 0u;
             bool fix = false, dyn = false, sure = false;
             if (screen) {
-                double u, v;                              // derotation (a wave-uniform branch) in double, then the float32 screen
-                derot_apply(raw[r][j], dp, W, H, yb + r, xb + j, &u, &v);
-                sure = phi_pixel_screen((float)u, (float)v, xb + j, yb + r, foex, foey, notsky, scr, &fix, &dyn);
+                float uf = (float)raw[r][j].x, vf = (float)raw[r][j].y;
+                if constexpr (ROT) {                      // derotation (a wave-uniform branch) in double, then the float32 screen
+                    double u, v;
+                    derot_apply(raw[r][j], dp, W, H, yb + r, xb + j, &u, &v);
+                    uf = (float)u; vf = (float)v;
+                }
+                sure = phi_pixel_screen(uf, vf, dxf[j], dyf[r], notsky, scr, &fix, &dyn);
             }
-            if (!sure) todo |= bit;
-            else { if (fix) fixb |= bit; if (dyn) dynb |= bit; }
+            const unsigned m = sure ? bit : 0u;           // selects, not branches: this loop is the kernel's whole cost
+            fixb |= fix ? m : 0u;
+            dynb |= dyn ? m : 0u;
+            todo |= bit ^ m;
         }
     }
     // Pass 2 (rare when the screen is on): the exact path, out of line, one pixel at a time; the pixel's inputs are re-read
@@ -490,17 +478,16 @@ __global__ __launch_bounds__(256) void k_phi_mask(const FlowT* __restrict__ flow
 }
 
 // The screen is usable when neither phi nor max(phi) is requested and the thresholds are in the regime where
-// "lo" (phi < dyn_a - (dyn_b + dyn_c/mag)) can never fire and both angle thresholds lie in [0, 180).
+// "lo" (phi < dyn_a - (dyn_b + dyn_c/mag)) can never fire, the fixed threshold lies in (0, 80) degrees and the dynamic one is >= 0.
 static PhiScreen phi_screen(const mav_thr_params& t, const double* phi, const unsigned long long* max_phi_bits)
 {
     PhiScreen s{};
-    const bool ok = !phi && !max_phi_bits && t.fixed_deg >= 0.0 && t.fixed_deg < 179.0 && t.dyn_a - t.dyn_b <= 0.0 &&
+    const bool ok = !phi && !max_phi_bits && t.fixed_deg > 0.0 && t.fixed_deg < 80.0 && t.dyn_a - t.dyn_b <= 0.0 &&
                     t.dyn_c >= 0.0 && t.dyn_a + t.dyn_b >= 0.0 && t.fixed_min_mag > 1e-3 && t.dyn_min_mag > 1e-3 &&
                     t.fixed_min_mag < 1e6 && t.dyn_min_mag < 1e6 && t.dyn_c < 1e6 && t.dyn_a + t.dyn_b < 1e3;
     { const char* e = getenv("MAVFLOW_NO_SCREEN"); s.enabled = ok && !(e && atoi(e) != 0); }
-    s.cos_fixed = (float)cos(t.fixed_deg * 3.141592653589793238462643383279502884 / 180.0);
-    s.fixed_tan = t.fixed_deg > 0.0 && t.fixed_deg < 80.0;
-    s.tan_fixed = s.fixed_tan ? (float)tan(t.fixed_deg * 3.141592653589793238462643383279502884 / 180.0) : 0.f;
+    s.tan_fixed = ok ? (float)tan(t.fixed_deg * 3.141592653589793238462643383279502884 / 180.0) : 0.f;
+    s.margin_fixed = MAV_SCREEN_TAN_MARGIN * (1.f + s.tan_fixed);
     s.fmm2 = (float)(t.fixed_min_mag * t.fixed_min_mag);
     s.dmm2 = (float)(t.dyn_min_mag * t.dyn_min_mag);
     s.dyn_ab = (float)(t.dyn_a + t.dyn_b);
@@ -515,15 +502,10 @@ static void launch_phi_mask_t(hipStream_t st, const FlowT* flow, const DerotPara
 {
     const PhiScreen scr = phi_screen(thr, phi, max_phi_bits);
     const bool vec = W % 4 == 0 && (((uintptr_t)sky | (uintptr_t)mask_fixed | (uintptr_t)mask_dyn) & 3) == 0;
-    if (vec) {
-        dim3 grid((W / 4 + 63) / 64, (H + 15) / 16, B);
-        hipLaunchKernelGGL((k_phi_mask<FlowT, 4>), grid, dim3(256), 0, st, flow, derot, foe, sky, W, H, thr, scr, phi, mask_fixed,
-                           mask_dyn, box_acc, max_phi_bits);
-    } else {
-        dim3 grid((W + 63) / 64, (H + 15) / 16, B);
-        hipLaunchKernelGGL((k_phi_mask<FlowT, 1>), grid, dim3(256), 0, st, flow, derot, foe, sky, W, H, thr, scr, phi, mask_fixed,
-                           mask_dyn, box_acc, max_phi_bits);
-    }
+    const dim3 grid(vec ? (W / 4 + 63) / 64 : (W + 63) / 64, (H + 15) / 16, B);
+    auto k = vec ? (derot ? k_phi_mask<FlowT, 4, true> : k_phi_mask<FlowT, 4, false>)
+                 : (derot ? k_phi_mask<FlowT, 1, true> : k_phi_mask<FlowT, 1, false>);
+    hipLaunchKernelGGL(k, grid, dim3(256), 0, st, flow, derot, foe, sky, W, H, thr, scr, phi, mask_fixed, mask_dyn, box_acc, max_phi_bits);
 }
 void launch_phi_mask_f32(hipStream_t st, const float* flow, const DerotParams* derot, const double* foe, const uint8_t* sky,
                          int B, int W, int H, mav_thr_params thr, double* phi, uint8_t* mask_fixed, uint8_t* mask_dyn,
