@@ -132,6 +132,11 @@ int mav_optimize_window(mav_ctx*, const uint8_t* img, int batch, const int32_t* 
  * src/processor.py:350-351) or for a bool mask (mask_value 1).  gt: any u8 image.
  * counts (batch,4) = positives, negatives, true positives, false positives. */
 int mav_tpr_fpr_counts(mav_ctx*, const uint8_t* gt, const uint8_t* mask, int mask_value, int batch, int64_t* counts);
+/* The same counts for the two masks the most recent mav_detect / mav_process_batch / mav_phi_mask(_f32) call on this context
+ * produced, which are still resident on the device: the validation tail of the loop [src/processor.py:350-351] without moving
+ * the masks again.  gt (batch, H, W) u8; counts_fixed / counts_dyn (batch, 4) each, either may be NULL.  MAV_ERR_STATE when
+ * no such call precedes or its batch differs. */
+int mav_last_masks_tpr_fpr(mav_ctx*, const uint8_t* gt, int mask_value, int batch, int64_t* counts_fixed, int64_t* counts_dyn);
 
 /* The fused loop body of Processor.run_detection [src/processor.py:305-341] for `batch` pairs:
  * frames -> flow -> (derotate) -> FoE -> phi -> masks -> box. omega/dt NULL = no rotation (dt = 1);

@@ -189,6 +189,8 @@ struct mav_ctx {
     hipStream_t copy_stream = nullptr;   // uploads that overlap the compute stream (mav_upload_async / mav_upload_fence)
     hipEvent_t copy_done = nullptr, compute_mark = nullptr;
     const float* last_flow = nullptr;    // where the latest farneback / process_batch call wrote its flow (mav_last_flow_dev)
+    const uint8_t *last_mf = nullptr, *last_md = nullptr;   // masks of the latest host-pointer detection call, still in their
+    int last_mask_batch = 0;                                // staging blocks (mav_last_masks_tpr_fpr)
     std::vector<Layer> layers;
     PolyCoef pc;
     // workspace (group slots)
@@ -853,6 +855,7 @@ static int check_batch(mav_ctx* c, int batch, const char* fn)
     if (batch < 1 || batch > c->max_batch) return fail(MAV_ERR_ARG, "%s: batch %d outside [1, %d]", fn, batch, c->max_batch);
     HIPCHK(hipSetDevice(c->device));
     c->scratch_next = 0;              // a new host-pointer call: its staging buffers start again at block 0
+    c->last_mf = c->last_md = nullptr; c->last_mask_batch = 0;     // ... and may overwrite the previous call's masks
     return MAV_OK;
 }
 
@@ -918,6 +921,7 @@ extern "C" int mav_phi_mask(mav_ctx* c, const double* flow, const double* foe, c
     CHK(detect_dev(c, nullptr, df.as<double>(), nullptr, nullptr, dsky.as<uint8_t>(), batch, nullptr, &t, dfoe.as<double>(),
                    dphi.as<double>(), dmf.as<uint8_t>(), dmd.as<uint8_t>(), max_phi ? c->u64_scratch : nullptr, nullptr, nullptr,
                    nullptr));
+    c->last_mf = dmf.as<uint8_t>(); c->last_md = dmd.as<uint8_t>(); c->last_mask_batch = batch;
     if (phi) CHK(download(c, phi, dphi.p, n * sizeof(double)));
     if (mask_fixed) CHK(download(c, mask_fixed, dmf.p, n));
     if (mask_dyn) CHK(download(c, mask_dyn, dmd.p, n));
@@ -971,6 +975,7 @@ extern "C" int mav_phi_mask_f32(mav_ctx* c, const float* flow, const double* foe
     CHK(detect_dev(c, df.as<float>(), nullptr, mode, nullptr, dsky.as<uint8_t>(), batch, nullptr, &t, dfoe.as<double>(),
                    dphi.as<double>(), dmf.as<uint8_t>(), dmd.as<uint8_t>(), max_phi ? c->u64_scratch : nullptr, nullptr, nullptr,
                    nullptr));
+    c->last_mf = dmf.as<uint8_t>(); c->last_md = dmd.as<uint8_t>(); c->last_mask_batch = batch;
     // the kernel stores the float32 angles widened to double (one phi layout for both arithmetic types): narrow them back, exactly
     std::vector<double> wide;
     if (phi) { wide.resize(n); CHK(download(c, wide.data(), dphi.p, n * sizeof(double))); }
@@ -1205,12 +1210,35 @@ static int process_host(mav_ctx* c, const char* fn, const uint8_t* prev, const u
     if (!flow_in) CHK(mav_farneback_dev(c, dp.as<uint8_t>(), dn.as<uint8_t>(), batch, dflow.as<float>()));
     CHK(mav_detect_dev(c, dflow.as<float>(), ds.as<uint32_t>(), dom.as<double>(), ddt.as<double>(), df0.as<uint8_t>(),
                        dsky.as<uint8_t>(), batch, &f, tp, dphi.as<double>(), dmf.as<uint8_t>(), dmd.as<uint8_t>(), dres.as<mav_result>()));
+    c->last_mf = dmf.as<uint8_t>(); c->last_md = dmd.as<uint8_t>(); c->last_mask_batch = batch;
     if (flow_out) CHK(download(c, flow_out, dflow.p, n * 2 * sizeof(float)));
     if (phi) CHK(download(c, phi, dphi.p, n * sizeof(double)));
     if (mask_fixed) CHK(download(c, mask_fixed, dmf.p, n));
     if (mask_dyn) CHK(download(c, mask_dyn, dmd.p, n));
     CHK(download(c, results, dres.p, sizeof(mav_result) * batch));
     return mav_sync(c);
+}
+
+extern "C" int mav_last_masks_tpr_fpr(mav_ctx* c, const uint8_t* gt, int mask_value, int batch, int64_t* counts_fixed, int64_t* counts_dyn)
+{
+    if (!c || !gt) return fail(MAV_ERR_ARG, "mav_last_masks_tpr_fpr: NULL argument");
+    if (mask_value < 1 || mask_value > 65535) return fail(MAV_ERR_ARG, "mav_last_masks_tpr_fpr: mask_value %d outside [1, 65535]", mask_value);
+    if (!c->last_mask_batch || batch != c->last_mask_batch || (counts_fixed && !c->last_mf) || (counts_dyn && !c->last_md))
+        return fail(MAV_ERR_STATE, "mav_last_masks_tpr_fpr: no masks of a %d-pair detection call are resident", batch);
+    HIPCHK(hipSetDevice(c->device));
+    // the ground truth goes into the NEXT free staging block: the previous call's blocks (its masks among them) stay untouched
+    const uint8_t *mf = c->last_mf, *md = c->last_md;
+    DevBuf dg;
+    CHK(dg.upload(c, gt, c->n0 * batch));
+    for (int k = 0; k < 2; k++) {
+        int64_t* out = k == 0 ? counts_fixed : counts_dyn;
+        if (!out) continue;
+        launch_tpr_fpr(c->stream, dg.as<uint8_t>(), k == 0 ? mf : md, (unsigned)mask_value, batch, c->W, c->H, c->u64_scratch);
+        CHK(check_launch("tpr_fpr"));
+        CHK(download(c, out, c->u64_scratch, sizeof(int64_t) * 4 * batch));
+        CHK(mav_sync(c));            // u64_scratch is reused by the second pass
+    }
+    return MAV_OK;
 }
 
 extern "C" int mav_process_batch(mav_ctx* c, const uint8_t* prev, const uint8_t* next, const uint32_t* samples, const double* omega,
@@ -1238,6 +1266,7 @@ static int layer_of(mav_ctx* c, int k, const Layer** l)
     if (k < 0 || k >= (int)c->layers.size()) return fail(MAV_ERR_ARG, "layer %d out of range", k);
     HIPCHK(hipSetDevice(c->device));
     c->scratch_next = 0;
+    c->last_mf = c->last_md = nullptr; c->last_mask_batch = 0;
     *l = &c->layers[k];
     return MAV_OK;
 }

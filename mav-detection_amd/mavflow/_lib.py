@@ -49,7 +49,7 @@ EXPORTS = [
     "mav_stage_polyexp", "mav_stage_update_matrices", "mav_stage_blur_iter",
     "mav_analyze_pyramid", "mav_pyramid_levels", "mav_pyramid_dims", "mav_optimize_window", "mav_stage_pyramid_level",
     "mav_detect", "mav_detect_dev", "mav_last_flow_dev", "mav_foe_dense_f32", "mav_phi_mask_f32", "mav_stage_coefficients",
-    "mav_stage_phi_mask",
+    "mav_stage_phi_mask", "mav_last_masks_tpr_fpr",
 ]
 
 _lib = None
@@ -86,6 +86,7 @@ def load() -> C.CDLL:
     lib.mav_bbox.argtypes = [vp, vp, C.c_int, vp]
     lib.mav_window_max.argtypes = [vp, vp, C.c_int, vp]
     lib.mav_tpr_fpr_counts.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp]
+    lib.mav_last_masks_tpr_fpr.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
     lib.mav_analyze_pyramid.argtypes = [vp, vp, C.c_int, C.c_double, vp]
     lib.mav_pyramid_levels.argtypes = [vp, C.c_double]
     lib.mav_pyramid_dims.argtypes = [vp, C.c_double, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -451,6 +452,15 @@ class Context:
         frame0 = None if frame0 is None else _arr(np.asarray(frame0).reshape(B).astype(np.uint8), np.uint8)
         sky = None if sky is None else _arr(np.asarray(sky).reshape(B, self.H, self.W).astype(np.uint8), np.uint8)
         return samples, omega, dt, frame0, sky
+
+    def last_masks_tpr_fpr(self, gt, mask_value: int = 255):
+        """calculate_tpr_fpr counts of BOTH masks of the most recent detect / process_batch / phi_mask call, taken where they
+        still are (on the device): ((batch, 4) fixed, (batch, 4) dynamic) = positives, negatives, true / false positives."""
+        gt = self._imgs(gt, "gt")
+        B = gt.shape[0]
+        cf, cd = np.empty((B, 4), np.int64), np.empty((B, 4), np.int64)
+        check(self.lib.mav_last_masks_tpr_fpr(self.h, _ptr(gt), int(mask_value), B, _ptr(cf), _ptr(cd)))
+        return cf, cd
 
     def process_batch(self, prev, nxt, samples, omega=None, dt=None, sky=None, foe_params=None, thr_params=None,
                       want_flow=True, want_phi=False, want_masks=True, frame0=None):

@@ -51,21 +51,42 @@ def calculate_tpr_fpr(gt_img: np.ndarray, img: np.ndarray) -> Tuple[float, float
     device as numpy would; anything else (other values, or a uint8 image whose product with gt would wrap) is rejected
     rather than guessed at."""
     gt = np.ascontiguousarray(gt_img, np.uint8)
-    m = np.asarray(img)
-    mask = (m != 0).astype(np.uint8)
-    if m.dtype == np.bool_:
-        value = 1
-    else:
-        values = np.unique(m[m != 0])
-        if values.size > 1 or (values.size == 1 and values[0] not in (1, 255)):
-            raise ValueError("calculate_tpr_fpr: detection image must be a bool mask, a 0/1 mask or 255 * mask")
-        value = int(values[0]) if values.size else 1
-        if value == 255 and m.dtype.itemsize == 1:
-            raise ValueError("calculate_tpr_fpr: a uint8 255-image would wrap in gt * img; pass 255 * mask (int) as the reference does")
+    mask, value = _mask_and_value(img)
     H, W = gt.shape
-    pos, neg, tp, fp = (int(v) for v in _ctx(W, H).tpr_fpr_counts(gt, mask, value)[0])
+    return _rates(_ctx(W, H).tpr_fpr_counts(gt, mask, value)[0])
+
+
+def _mask_and_value(img: np.ndarray):
+    """(u8 0/1 mask, the value its set pixels carry in the reference's product gt * img): bool -> 1, 0/1 -> 1, 255 * mask -> 255.
+    Three reductions instead of a sort: all nonzero entries equal the maximum iff sum == count * max (entries are >= 0)."""
+    m = np.asarray(img)
+    if m.dtype == np.bool_:
+        return m.view(np.uint8), 1
+    mask = (m != 0).astype(np.uint8)
+    n = int(np.count_nonzero(mask))
+    if n == 0:
+        return mask, 1
+    top, low = int(m.max()), int(m.min())
+    if low < 0 or top not in (1, 255) or int(m.sum(dtype=np.int64)) != n * top:
+        raise ValueError("calculate_tpr_fpr: detection image must be a bool mask, a 0/1 mask or 255 * mask")
+    if top == 255 and m.dtype.itemsize == 1:
+        raise ValueError("calculate_tpr_fpr: a uint8 255-image would wrap in gt * img; pass 255 * mask (int) as the reference does")
+    return mask, top
+
+
+def _rates(counts):
+    pos, neg, tp, fp = (int(v) for v in counts)
     with np.errstate(all="ignore"):
         return (np.float64(tp) / np.float64(pos), np.float64(fp) / np.float64(neg))
+
+
+def tpr_fpr_of_last_masks(gt_img: np.ndarray, mask_value: int = 255):
+    """calculate_tpr_fpr(gt, 255 * estimate_fixed) and calculate_tpr_fpr(gt, 255 * total_mask) (processor.py:350-351) for the
+    masks the last detection call on this frame size's context left on the device: ((tpr_fixed, fpr_fixed), (tpr, fpr))."""
+    gt = np.ascontiguousarray(gt_img, np.uint8)
+    H, W = gt.shape
+    cf, cd = _ctx(W, H).last_masks_tpr_fpr(gt, mask_value)
+    return _rates(cf[0]), _rates(cd[0])
 
 
 def to_int(img: np.ndarray, type: type = np.uint8, normalize: bool = False, max_value: float = None) -> np.ndarray:

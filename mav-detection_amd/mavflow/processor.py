@@ -35,6 +35,8 @@ class SyntheticDataset:
         self.dangle = np.asarray(dangle, np.float64)
         self.seed = seed
         self._pairs = {}
+        self._gt32 = {}
+        self._seg = self._sky = self._depth = None       # the constant images are built once, like files read once
         self._ctx: Optional[_lib.Context] = None
         self._frame_cursor = 0
 
@@ -61,19 +63,26 @@ class SyntheticDataset:
         return self._ctx.farneback(f0, f1)[0]
 
     def get_gt_of(self, i: int) -> np.ndarray:
-        return self._pair(i)[2].astype(np.float32)
+        if i not in self._gt32:
+            self._gt32[i] = self._pair(i)[2].astype(np.float32)
+        return self._gt32[i]
 
     def get_segmentation(self, i: int) -> np.ndarray:
-        W, H = self.capture_size
-        seg = np.zeros((H, W, 3), np.uint8)
-        seg[H // 4:H // 4 + 24, W // 4:W // 4 + 24] = 255
-        return seg
+        if self._seg is None:
+            W, H = self.capture_size
+            self._seg = np.zeros((H, W, 3), np.uint8)
+            self._seg[H // 4:H // 4 + 24, W // 4:W // 4 + 24] = 255
+        return self._seg
 
     def get_sky_segmentation(self, i: int) -> np.ndarray:
-        return np.zeros((self.capture_size[1], self.capture_size[0]), dtype=bool)
+        if self._sky is None:
+            self._sky = np.zeros((self.capture_size[1], self.capture_size[0]), dtype=bool)
+        return self._sky
 
     def get_depth(self, i: int) -> np.ndarray:
-        return np.ones((self.capture_size[1], self.capture_size[0]), np.float32)
+        if self._depth is None:
+            self._depth = np.ones((self.capture_size[1], self.capture_size[0]), np.float32)
+        return self._depth
 
     def validate_sky_segment(self, sky_mask, depth_buffer) -> Tuple[float, float]:
         return (0.0, 0.0)
@@ -115,25 +124,37 @@ class Processor:
         return self.frame_index < self.dataset.N - 1 and not self.is_exiting
 
     # -- validation tail shared by the loops (processor.py:343-362) ---------------------------------------------------
-    def _fill_result(self, i: int, foe_dense, estimate_fixed, total_mask, sky_scores) -> FrameResult:
+    def _fill_result(self, i: int, foe_dense, estimate_fixed, total_mask, sky_scores, masks_on_device: bool = False) -> FrameResult:
         r = FrameResult()
         r.foe_dense = foe_dense
         r.foe_gt = utils.assert_type(self.dataset.get_gt_foe(i))
         segmentation = self.dataset.get_segmentation(i)[..., 0]
+        if masks_on_device:      # first thing: both masks are still where the detection call left them on the device, and stay
+            # there only until the next call on that context -- count there (mav_last_masks_tpr_fpr) instead of re-uploading
+            (r.tpr_fixed, r.fpr_fixed), (r.tpr, r.fpr) = im_helpers.tpr_fpr_of_last_masks(segmentation, 255)
         # ground-truth flow of the drone: derotated at the drone's pixels only (pointwise, same values as derotating the frame)
         gt = utils.assert_type(self.dataset.get_gt_of(i))
         rows, cols = np.nonzero(segmentation > 127)
         with np.errstate(all="ignore"):
             drone_flow_avg_gt = np.average(self.detector.derotate_at(i - self.frame_step_size, i, gt[rows, cols], rows, cols), axis=0)
-        center = im_helpers.get_simple_bounding_box(segmentation).get_center()
+        center = self._gt_center(segmentation)
         r.center_phi = np.rad2deg(np.arctan2(center[1] - r.foe_gt[1], center[0] - r.foe_gt[0]))
-        r.tpr_fixed, r.fpr_fixed = im_helpers.calculate_tpr_fpr(segmentation, 255 * estimate_fixed)     # as processor.py:350-351
-        r.tpr, r.fpr = im_helpers.calculate_tpr_fpr(segmentation, 255 * total_mask)
+        if not masks_on_device:
+            r.tpr_fixed, r.fpr_fixed = im_helpers.calculate_tpr_fpr(segmentation, 255 * estimate_fixed)     # as processor.py:350-351
+            r.tpr, r.fpr = im_helpers.calculate_tpr_fpr(segmentation, 255 * total_mask)
         r.sky_tpr, r.sky_fpr = sky_scores
         r.drone_flow_pixels = (drone_flow_avg_gt[0], drone_flow_avg_gt[1])
         r.drone_size_pixels = np.sum(segmentation > 127)
         r.time = self.dataset.get_time(i)
         return r
+
+    def _gt_center(self, segmentation: np.ndarray):
+        """get_simple_bounding_box(segmentation).get_center() (processor.py:346-347); datasets whose segmentation image is one
+        constant object (SyntheticDataset) have it computed once."""
+        key = id(segmentation)
+        if getattr(self, "_center_key", None) != key:
+            self._center_key, self._center = key, im_helpers.get_simple_bounding_box(segmentation).get_center()
+        return self._center
 
     def _rates(self, i: int):
         dt = self.dataset.get_delta_time(i)
@@ -163,7 +184,8 @@ class Processor:
                              foe_params=self.focus_of_expansion._foe_params(1000))
             rec = out["results"][0]
             self.estimate_fixed, self.total_mask = out["mask_fixed"][0], out["mask_dyn"][0]
-            r = self._fill_result(i, (float(rec["foe"][0]), float(rec["foe"][1])), self.estimate_fixed, self.total_mask, sky)
+            r = self._fill_result(i, (float(rec["foe"][0]), float(rec["foe"][1])), self.estimate_fixed, self.total_mask, sky,
+                                  masks_on_device=True)
             self.detection_results[i] = r
             self.config.results[i] = r
             self.frame_index += 1
