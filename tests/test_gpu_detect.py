@@ -274,3 +274,34 @@ def test_rccl_allgather_entry_points_world_size_1(mav):
         got = dst.download(_lib.RESULT_DTYPE, (4,))
         _lib.check(c.lib.mav_comm_destroy(comm))
     assert got.tobytes() == rec.tobytes()
+
+
+def test_validation_counts_on_resident_masks(mav, golden):
+    """mav_last_masks_tpr_fpr: calculate_tpr_fpr (im_helpers.py:244-252) of both masks of the previous detection call, taken
+    where that call left them on the device -- equal to the counts of the downloaded masks and to the oracle's rates; refused
+    (MAV_ERR_STATE) once another call has re-used the staging blocks."""
+    from mavflow import _lib
+    W, H = 640, 480
+    fl = synth.synthetic_flow(W, H, seed=3)
+    smp = synth.foe_samples(W, H, 0)
+    gt = np.zeros((H, W), np.uint8)
+    gt[H // 4:H // 4 + 24, W // 4:W // 4 + 24] = 255
+    with _lib.Context(W, H, 1) as c:
+        out = c.detect(fl, smp)
+        ys, xs = np.nonzero(out["mask_dyn"][0] & (gt == 0))
+        gt[ys[:50], xs[:50]] = 90                           # 0 < gt <= 127 under set mask pixels: counted by gt * 255 > 127, not by gt > 127
+        cf, cd = c.last_masks_tpr_fpr(gt, 255)
+        assert np.array_equal(cf, c.tpr_fpr_counts(gt, out["mask_fixed"], 255))
+        with pytest.raises(_lib.MavflowError):              # tpr_fpr_counts above re-used the staging blocks
+            c.last_masks_tpr_fpr(gt, 255)
+        out = c.detect(fl, smp)
+        cf, cd = c.last_masks_tpr_fpr(gt, 255)
+        c1 = c.last_masks_tpr_fpr(gt, 1)[1]                 # a second look is allowed: it only appends a block
+        with pytest.raises(_lib.MavflowError):
+            c.last_masks_tpr_fpr(np.stack([gt, gt]), 255)   # batch mismatch (and larger than the context's)
+    for counts, mask, val in ((cf[0], out["mask_fixed"][0], 255), (cd[0], out["mask_dyn"][0], 255), (c1[0], out["mask_dyn"][0], 1)):
+        with np.errstate(all="ignore"):
+            exp = fo.calculate_tpr_fpr(gt, val * mask.astype(np.int64))
+            got = (counts[2] / counts[0], counts[3] / counts[1])
+        assert np.array(got).tobytes() == np.array(exp, np.float64).tobytes(), (val, counts)
+    assert cd[0][2] != c1[0][2]                             # the gt = 90 block separates the two multipliers
