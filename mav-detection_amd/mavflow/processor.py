@@ -36,6 +36,7 @@ class SyntheticDataset:
         self.seed = seed
         self._pairs = {}
         self._gt32 = {}
+        self._bgr = {}
         self._seg = self._sky = self._depth = None       # the constant images are built once, like files read once
         self._ctx: Optional[_lib.Context] = None
         self._frame_cursor = 0
@@ -50,14 +51,16 @@ class SyntheticDataset:
         return f0, f1
 
     def get_frame(self) -> np.ndarray:
-        f = self._pair(self._frame_cursor)[1]
+        i = self._frame_cursor % self.N
         self._frame_cursor += 1
-        return np.repeat(f[..., None], 3, axis=2)
+        if i not in self._bgr:
+            self._bgr[i] = np.repeat(self._pair(i)[1][..., None], 3, axis=2)
+        return self._bgr[i]
 
     def get_flow_uv(self, i: int) -> np.ndarray:
         f0, f1, truth = self._pair(i)
         if not self.use_farneback:
-            return truth.astype(np.float32)
+            return self.get_gt_of(i)                     # the analytic field, float32 (what a .flo file would hold)
         if self._ctx is None:
             self._ctx = _lib.Context(self.capture_size[0], self.capture_size[1], 1)
         return self._ctx.farneback(f0, f1)[0]
@@ -128,13 +131,12 @@ class Processor:
         r = FrameResult()
         r.foe_dense = foe_dense
         r.foe_gt = utils.assert_type(self.dataset.get_gt_foe(i))
-        segmentation = self.dataset.get_segmentation(i)[..., 0]
+        segmentation, rows, cols = self._segmentation(i)
         if masks_on_device:      # first thing: both masks are still where the detection call left them on the device, and stay
             # there only until the next call on that context -- count there (mav_last_masks_tpr_fpr) instead of re-uploading
             (r.tpr_fixed, r.fpr_fixed), (r.tpr, r.fpr) = im_helpers.tpr_fpr_of_last_masks(segmentation, 255)
         # ground-truth flow of the drone: derotated at the drone's pixels only (pointwise, same values as derotating the frame)
         gt = utils.assert_type(self.dataset.get_gt_of(i))
-        rows, cols = np.nonzero(segmentation > 127)
         with np.errstate(all="ignore"):
             drone_flow_avg_gt = np.average(self.detector.derotate_at(i - self.frame_step_size, i, gt[rows, cols], rows, cols), axis=0)
         center = self._gt_center(segmentation)
@@ -144,9 +146,20 @@ class Processor:
             r.tpr, r.fpr = im_helpers.calculate_tpr_fpr(segmentation, 255 * total_mask)
         r.sky_tpr, r.sky_fpr = sky_scores
         r.drone_flow_pixels = (drone_flow_avg_gt[0], drone_flow_avg_gt[1])
-        r.drone_size_pixels = np.sum(segmentation > 127)
+        r.drone_size_pixels = np.int64(rows.size)              # == np.sum(segmentation > 127), a numpy integer as in the reference
         r.time = self.dataset.get_time(i)
         return r
+
+    def _segmentation(self, i: int):
+        """Channel 0 of the dataset's segmentation image, contiguous, with the coordinates of its drone pixels (> 127).  Derived
+        once per image OBJECT: a dataset that hands out the same array every frame (SyntheticDataset) pays once, one that reads
+        a new PNG per frame pays per frame, as the reference's loop does (processor.py:332,344-345)."""
+        seg3 = self.dataset.get_segmentation(i)
+        if getattr(self, "_seg_key", None) is not seg3:
+            seg = np.ascontiguousarray(seg3[..., 0])
+            rows, cols = np.nonzero(seg > 127)
+            self._seg_key, self._seg_val = seg3, (seg, rows, cols)
+        return self._seg_val
 
     def _gt_center(self, segmentation: np.ndarray):
         """get_simple_bounding_box(segmentation).get_center() (processor.py:346-347); datasets whose segmentation image is one
