@@ -24,7 +24,7 @@ static __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v <
 // is 60 tiles and without strips the reuse distance exceeds the L2.  Speed only: every tile is computed exactly once and
 // nothing depends on the order.  Grid = n_tiles rounded up to a multiple of 8.
 // ------------------------------------------------------------------------------------------------------------
-struct TileMap { int tiles_x, tiles_y, per_img, n_tiles, strip_w, xcd; };   // xcd = 0: plain row-major order (A/B switch)
+struct TileMap { int tiles_x, tiles_y, per_img, n_tiles, strip_w, xcd, ty0; };   // xcd = 0: plain row-major order; ty0: first tile row (a band launch)
 static __device__ __forceinline__ bool tile_of_block(const TileMap& tm, int* s, int* tx, int* ty)
 {
     const int per = ((int)gridDim.x + 7) >> 3;
@@ -38,17 +38,20 @@ static __device__ __forceinline__ bool tile_of_block(const TileMap& tm, int* s, 
     const int x_base = st * tm.strip_w;
     const int sw = min(tm.strip_w, tm.tiles_x - x_base);
     const int row = tr / sw;
-    *s = img; *ty = row; *tx = x_base + tr - row * sw;
+    *s = img; *ty = row + tm.ty0; *tx = x_base + tr - row * sw;
     return true;
 }
 static int g_strip_override = -1;                                // MAVFLOW_STRIP: tuning experiments only
-static TileMap make_tile_map(int w, int h, int G, int tile_w, int tile_h, const char* ab_env = nullptr)
+// rows [ty0, ty1) of the tile grid only (a band of the image); ty1 < 0 = all rows
+static TileMap make_tile_map(int w, int h, int G, int tile_w, int tile_h, int ty0 = 0, int ty1 = -1)
 {
     TileMap tm;
     tm.xcd = 1;
-    if (ab_env) { const char* e = getenv(ab_env); if (e) tm.xcd = atoi(e) != 0; }
     tm.tiles_x = (w + tile_w - 1) / tile_w;
     tm.tiles_y = (h + tile_h - 1) / tile_h;
+    tm.ty0 = ty0 > 0 ? (ty0 < tm.tiles_y ? ty0 : tm.tiles_y) : 0;
+    if (ty1 >= 0 && ty1 < tm.tiles_y) tm.tiles_y = ty1;
+    tm.tiles_y = tm.tiles_y > tm.ty0 ? tm.tiles_y - tm.ty0 : 0;
     tm.per_img = tm.tiles_x * tm.tiles_y;
     tm.n_tiles = tm.per_img * G;
     if (g_strip_override < 0) { const char* e = getenv("MAVFLOW_STRIP"); g_strip_override = e ? atoi(e) : 0; }
@@ -1056,19 +1059,34 @@ __global__ __launch_bounds__(256) void k_sweep_rc(const float* __restrict__ fin,
     }
 }
 
-static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+int blur_iter_tile_rows(int h) { return (h + FT_Y - 1) / FT_Y; }
+static bool blur_iter_vec_ok(int w, size_t M_stride, size_t R_stride, size_t f_stride, const void* M_in, const void* M_out, const void* R0,
+                             const void* R1, const void* flow)
+{
+    return (w % 4 == 0) && (M_stride % 4 == 0) && (R_stride % 4 == 0) && (f_stride % 4 == 0) && aligned16(M_in) && aligned16(M_out) &&
+           aligned16(R0) && aligned16(R1) && aligned16(flow);
+}
+bool blur_iter_bands_ok(int w, int winsize, size_t M_stride, size_t R_stride, size_t f_stride, const void* M_in, const void* M_out,
+                        const void* R0, const void* R1, const void* flow)
+{
+    return winsize / 2 == 6 && blur_iter_vec_ok(w, M_stride, R_stride, f_stride, M_in, M_out, R0, R1, flow);
+}
+
+// tile rows [ty0, ty1) only (ty1 < 0: the whole layer).  Band launches exist for the fast form only (blur_iter_bands_ok).
 void launch_blur_iter(hipStream_t st, const float* M_in, float* M_out, size_t M_stride, const float* R0, const float* R1,
-                      size_t R_stride, int G, int w, int h, int winsize, int do_update, int store_flow, float* flow, size_t f_stride)
+                      size_t R_stride, int G, int w, int h, int winsize, int do_update, int store_flow, float* flow, size_t f_stride,
+                      int ty0, int ty1)
 {
     int ext, pitch, plane;
     const int m = winsize / 2;
     const float scale = (float)(1.0 / ((double)winsize * winsize));
     dim3 grid((w + MAV_TILE - 1) / MAV_TILE, (h + MAV_TILE - 1) / MAV_TILE, G);
-    const bool vec_ok = (w % 4 == 0) && (M_stride % 4 == 0) && (R_stride % 4 == 0) && (f_stride % 4 == 0) && aligned16(M_in) &&
-                        aligned16(M_out) && aligned16(R0) && aligned16(R1) && aligned16(flow);
+    const bool vec_ok = blur_iter_vec_ok(w, M_stride, R_stride, f_stride, M_in, M_out, R0, R1, flow);
     if (m == 6 && vec_ok) {
-        const TileMap tm = make_tile_map(w, h, G, FT_X, FT_Y);
+        const TileMap tm = make_tile_map(w, h, G, FT_X, FT_Y, ty0, ty1);
+        if (tm.n_tiles == 0) return;
         hipLaunchKernelGGL(k_blur_iter_fast<6>, dim3(tile_grid(tm)), dim3(256), 0, st, M_in, M_out, M_stride, R0, R1, R_stride, w, h,
                            tm, scale, do_update, store_flow, flow, f_stride);
         return;

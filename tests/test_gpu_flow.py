@@ -259,3 +259,24 @@ def test_double_buffered_uploads_with_different_content(mav):
         c.sync()
         for k in range(N):
             assert np.array_equal(outs[k].download(np.float32, ref[k].shape), ref[k]), k
+
+
+@pytest.mark.parametrize("size", [(640, 480), (1920, 1080)])
+def test_banded_two_stream_sweeps_are_bit_identical(mav, size):
+    """Option "bands": the finest layer's sweeps split into skewed horizontal bands on two streams (consecutive sweeps of one
+    pair in flight together).  Same tiles, same arithmetic: the flow must equal the one-launch-per-sweep schedule bit for bit,
+    for one pair per call (latency path) and for per-pair sweeps inside a batch, repeatedly (ordering bugs are races)."""
+    from mavflow import _lib
+    W, H = size
+    prev, nxt = synth.make_batch(W, H, 3, distinct=3)
+    with _lib.Context(W, H, 3) as c:
+        c.set_option("bands", 1)
+        ref = c.farneback(prev, nxt)
+        one = c.farneback(prev[:1], nxt[:1])
+        for bands in (2, 3):
+            c.set_option("bands", bands)
+            for _ in range(3):
+                assert np.array_equal(c.farneback(prev, nxt), ref), bands
+            assert np.array_equal(c.farneback(prev[:1], nxt[:1]), one), bands
+        c.set_option("group", 2)                       # a group of 2 + a group of 1
+        assert np.array_equal(c.farneback(prev, nxt), ref)
