@@ -76,7 +76,9 @@ int mav_device_count(void);       /* <= 0 when no GPU is visible */
 /* Tuning: "group" = pairs per launch (>= 1, default 8); "group_fine" = pairs per launch for the finest layer's sweeps
  * (default 1: one pair's working set stays in the Infinity Cache; 0 = same as group); "recompute" = 1: sweeps rebuild M
  * from (R0, R1, flow) on the fly instead of storing it (default 0); "pipeline" = 1: a second work set and stream prepare
- * group i + 1 (pyramid, expansions) while group i's finest-layer sweeps run (default 0: measured slower). MAV_ERR_ARG for unknown names. */
+ * group i + 1 (pyramid, expansions) while group i's finest-layer sweeps run (default 0: measured slower); "bands" = J in [1, 8]: the
+ * finest layer's sweeps of a pair run band by band over J skewed horizontal bands (default: 1 up to ~2.6 Mpx, above that as many
+ * bands as keep one band's working set inside the Infinity Cache). MAV_ERR_ARG for unknown names. */
 int mav_set_option(mav_ctx*, const char* name, long value);
 int mav_num_layers(const mav_ctx*);
 int mav_layer_dims(const mav_ctx*, int k, int* w, int* h, int* ksize, double* sigma);

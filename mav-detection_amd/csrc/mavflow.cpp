@@ -204,9 +204,7 @@ struct mav_ctx {
     } ws[2];
     int nsets = 1;
     bool pipeline = false;           // option "pipeline" (off: measured 2 % slower): prepare group i + 1 while group i sweeps
-    int bands = 2;                   // option "bands": horizontal bands per finest-layer sweep, alternate sweeps on two streams (1 = off)
-    std::vector<hipEvent_t> band_ev; // [iteration][band] completion events of the banded schedule
-    hipEvent_t band_join = nullptr;
+    int bands = 1;                   // option "bands": the finest layer's sweeps in band-major order over this many skewed bands
     hipStream_t prep_stream = nullptr;
     hipEvent_t prep_done[2] = {nullptr, nullptr}, fine_done[2] = {nullptr, nullptr}, call_begin = nullptr;
     size_t htmp_stride = 0;
@@ -302,8 +300,6 @@ extern "C" int mav_destroy(mav_ctx* c)
     if (c->copy_done) hipEventDestroy(c->copy_done);
     if (c->compute_mark) hipEventDestroy(c->compute_mark);
     for (hipEvent_t e : {c->prep_done[0], c->prep_done[1], c->fine_done[0], c->fine_done[1], c->call_begin}) if (e) hipEventDestroy(e);
-    for (hipEvent_t e : c->band_ev) if (e) hipEventDestroy(e);
-    if (c->band_join) hipEventDestroy(c->band_join);
     if (c->prep_stream) hipStreamDestroy(c->prep_stream);
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -387,8 +383,15 @@ extern "C" int mav_create(mav_ctx** out, int device, int W, int H, int max_batch
     if (const char* e = getenv("MAVFLOW_GROUP_FINE")) { int v = atoi(e); if (v >= 0) c->group_fine = v; }
     if (const char* e = getenv("MAVFLOW_PIPELINE")) c->pipeline = atoi(e) != 0;
     if (const char* e = getenv("MAVFLOW_BANDS")) { int v = atoi(e); if (v >= 1 && v <= 8) c->bands = v; }
-    // the Infinity-Cache argument only holds while one pair's finest-layer working set (80 B/px) fits in it
-    if ((size_t)W * H * 80 > (size_t)200 << 20) c->group_fine = 0;
+    // One pair's finest-layer working set (80 B/px) fits the 256 MB Infinity Cache up to ~2.6 Mpx.  Beyond that the pair is swept
+    // band by band (sweeps_band_major), bands of at most ~150 MB; MAVFLOW_BANDS=1 with MAVFLOW_GROUP_FINE=0 gives the batched form.
+    if ((size_t)W * H * 80 > (size_t)200 << 20 && !getenv("MAVFLOW_GROUP_FINE")) {
+        c->group_fine = 1;
+        if (!getenv("MAVFLOW_BANDS")) {
+            c->bands = (int)(((size_t)W * H * 80 + ((size_t)150 << 20) - 1) / ((size_t)150 << 20));
+            if (c->bands > 8) c->bands = 8;
+        }
+    }
     rc = alloc_group(c, group);
     if (rc != MAV_OK) return bail(rc);
     const size_t B = (size_t)max_batch;
@@ -578,51 +581,38 @@ static BlurParams blur_of(const mav_ctx* c, const Layer& l)
     return BlurParams{l.ksize, (l.ksize == 3 && l.sigma <= 0) ? 1 : 0, l.g, (double)c->W / l.w, (double)c->H / l.h};
 }
 
-// The finest layer's sweeps of one cache-resident sub-group, split into J horizontal bands and dealt to TWO streams.
-//
-// A per-pair sweep launch is ~1.6 residency rounds of workgroups that all start together: their load, sum and gather phases run
-// in lockstep (the memory system idles while they compute and vice versa -- measured: the phases' times ADD), and the second,
-// partial round leaves 40 % of the slots empty.  Two launches in flight that are out of phase fill both gaps, but two PAIRS in
-// flight do not fit the Infinity Cache.  So the two launches are consecutive sweeps of the SAME pair, which is legal on
-// disjoint bands with a skew: sweep `it` processes band j as tile rows [A_j - it, A_(j+1) - it) (16 pixel rows per tile row; the
-// first band starts at row 0, the last one ends at the bottom).  Sweep it + 1 on band j reads rows within 6 pixels of its own,
-// i.e. output of (it, j) and (it, j - 1) only, and the M ping-pong buffer it overwrites is read by (it, j + 1) no higher than
-// 6 pixels above tile row A_(j+1) - it, one tile row below what it writes: a one-tile-row skew (16 >= 6) makes both safe.
-// Even sweeps run on the compute stream, odd ones on the second stream; (it + 1, j) waits for the event of (it, j), which by
-// stream order covers (it, j - 1).  Every tile is computed exactly once, with the same tile grid: results are bit-identical
-// to the unbanded schedule (tests/test_gpu_flow.py).  At the end the compute stream waits for the second stream.
-static void sweeps_banded(mav_ctx* c, hipStream_t st, float* Min, float* Mout, const float* r0, const float* r1, int gs, int lw, int lh,
-                          int T, int J, float* fo, size_t fstride)
+// The finest layer's sweeps of one pair in BAND-MAJOR order, for frames whose per-pair working set (80 B per pixel: M in, M out,
+// R0, R1) does not fit the 256 MB Infinity Cache -- 664 MB at 3840x2160.  The image is cut into J horizontal bands of tile rows
+// and ALL sweeps of a band run before the next band starts, so that a band's M, R0 and R1 stay cache-resident across its sweeps
+// exactly as a whole 1080p pair does.  What makes this legal without recomputing halos is a skew: sweep `it` processes band j as
+// tile rows [A_j - it, A_(j+1) - it) (16 pixel rows per tile row; the first band starts at row 0, the last ends at the bottom).
+//   * reads: sweep it on band j needs sweep it - 1 within 6 pixels of its rows = output of (it - 1, j), just computed, and of
+//     (it - 1, j - 1), computed with the previous band;
+//   * the M ping-pong: (it, j) writes the buffer that (it - 1, j + 1) will read later, but only up to tile row A_(j+1) - it - 1,
+//     while that reader starts 6 pixels above tile row A_(j+1) - it + 1; and the rows of band j - 1 that (it, j) itself reads have
+//     been overwritten by (it + 1, j - 1) only up to one tile row above them.  A skew of one tile row (16 >= 6 pixels) covers both.
+// Every tile is computed exactly once on the same tile grid: results are bit-identical to the sweep-major schedule
+// (tests/test_gpu_flow.py).  One stream, no events.
+// (A two-stream variant of the same skew -- consecutive sweeps of one 1080p pair in flight together on different bands, to break
+// the lockstep of a per-pair launch -- was built, parity-green, and dropped: every cross-stream event wait costs ~6 us, 36.6 vs
+// 28.8 ms per 64 pairs.)
+static void sweeps_band_major(mav_ctx* c, hipStream_t st, int kid, float* Ma, float* Mb, const float* r0, const float* r1, int gs, int lw,
+                              int lh, int T, int J, float* fo, size_t fstride)
 {
     const size_t n0 = c->n0;
     const int I = c->fb.iterations;
-    if ((int)c->band_ev.size() < I * J) {
-        const size_t old = c->band_ev.size();
-        c->band_ev.resize((size_t)I * J, nullptr);
-        for (size_t i = old; i < c->band_ev.size(); i++) hipEventCreateWithFlags(&c->band_ev[i], hipEventDisableTiming);
-    }
-    if (!c->band_join) hipEventCreateWithFlags(&c->band_join, hipEventDisableTiming);
-    // the second stream joins behind whatever the compute stream has enqueued so far (the initial M of this sub-group)
-    hipEventRecord(c->band_join, st);
-    hipStreamWaitEvent(c->prep_stream, c->band_join, 0);
-    for (int it = 0; it < I; it++) {
-        const int upd = it < I - 1;
-        const hipStream_t s_it = (it & 1) ? c->prep_stream : st;
-        for (int j = 0; j < J; j++) {
-            const int a0 = (int)((long long)T * j / J), a1 = (int)((long long)T * (j + 1) / J);
+    for (int j = 0; j < J; j++) {
+        const int a0 = (int)((long long)T * j / J), a1 = (int)((long long)T * (j + 1) / J);
+        for (int it = 0; it < I; it++) {
+            const int upd = it < I - 1;
             int ty0 = j == 0 ? 0 : a0 - it, ty1 = j == J - 1 ? T : a1 - it;
             if (ty0 < 0) ty0 = 0;
-            if (ty1 < ty0) ty1 = ty0;
-            if (it > 0) hipStreamWaitEvent(s_it, c->band_ev[(size_t)(it - 1) * J + j], 0);
-            if (ty1 > ty0)
-                launch_blur_iter(s_it, Min, Mout, 5 * n0, r0, r1, 5 * n0, gs, lw, lh, c->fb.winsize, upd, !upd, fo, fstride, ty0, ty1);
-            hipEventRecord(c->band_ev[(size_t)it * J + j], s_it);
+            if (ty1 <= ty0) continue;
+            ProfScope ps(c, kid, st);
+            launch_blur_iter(st, (it & 1) ? Mb : Ma, (it & 1) ? Ma : Mb, 5 * n0, r0, r1, 5 * n0, gs, lw, lh, c->fb.winsize, upd, !upd, fo,
+                             fstride, ty0, ty1);
         }
-        if (upd) { float* t = Min; Min = Mout; Mout = t; }
     }
-    // whatever follows on the compute stream (the next sub-group's buffers are its own; the detection stage reads the flow)
-    // must see the last sweep, which ran on stream (I - 1) & 1
-    if ((I - 1) & 1) hipStreamWaitEvent(st, c->band_ev[(size_t)(I - 1) * J + (J - 1)], 0);
 }
 
 // Initial M and the `iterations` sweeps of layer k for g slots of work set w, on stream st.  flow_prev = the coarser layer's
@@ -682,13 +672,12 @@ static void layer_sweeps(mav_ctx* c, mav_ctx::WorkSet& w, hipStream_t st, int k,
         const float *r0 = w.R0 + (size_t)s0 * 5 * n0, *r1 = w.R1 + (size_t)s0 * 5 * n0;
         float* fo = fdst + (size_t)s0 * fstride;
         const int T = blur_iter_tile_rows(l.h);
-        // bands: one cache-resident sub-group at a time, on the compute stream, bands at least iterations + 2 tile rows high (the
-        // skewed band edges then never reach the top of the image), never while per-kernel profiling times launches one by one
-        const int J = (k == 0 && (m_per_sub || g == 1) && st == c->stream && !c->profiling && c->fb.iterations >= 2 &&
-                       T >= (c->fb.iterations + 2) * c->bands &&
+        // bands (finest layer, one pair per launch): at least iterations + 2 tile rows each, so that the skewed band edges never
+        // reach the top of the image
+        const int J = (k == 0 && (m_per_sub || g == 1) && gs == 1 && T >= (c->fb.iterations + 2) * c->bands &&
                        blur_iter_bands_ok(l.w, c->fb.winsize, 5 * n0, 5 * n0, fstride, Min, Mout, r0, r1, fo)) ? c->bands : 1;
         if (J > 1) {
-            sweeps_banded(c, st, Min, Mout, r0, r1, gs, l.w, l.h, T, J, fo, fstride);
+            sweeps_band_major(c, st, K_ITER, Min, Mout, r0, r1, gs, l.w, l.h, T, J, fo, fstride);
             continue;
         }
         for (int it = 0; it < c->fb.iterations; it++) {
