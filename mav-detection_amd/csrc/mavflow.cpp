@@ -205,6 +205,7 @@ struct mav_ctx {
     int nsets = 1;
     bool pipeline = false;           // option "pipeline" (off: measured 2 % slower): prepare group i + 1 while group i sweeps
     int bands = 1;                   // option "bands": the finest layer's sweeps in band-major order over this many skewed bands
+    int coarse_cache_mb = 220;       // coarse layers: pairs per launch capped so that the sweeps' working set stays below this (0 = no cap)
     hipStream_t prep_stream = nullptr;
     hipEvent_t prep_done[2] = {nullptr, nullptr}, fine_done[2] = {nullptr, nullptr}, call_begin = nullptr;
     size_t htmp_stride = 0;
@@ -383,12 +384,14 @@ extern "C" int mav_create(mav_ctx** out, int device, int W, int H, int max_batch
     if (const char* e = getenv("MAVFLOW_GROUP_FINE")) { int v = atoi(e); if (v >= 0) c->group_fine = v; }
     if (const char* e = getenv("MAVFLOW_PIPELINE")) c->pipeline = atoi(e) != 0;
     if (const char* e = getenv("MAVFLOW_BANDS")) { int v = atoi(e); if (v >= 1 && v <= 8) c->bands = v; }
+    if (const char* e = getenv("MAVFLOW_COARSE_MB")) { int v = atoi(e); if (v >= 0) c->coarse_cache_mb = v; }
     // One pair's finest-layer working set (80 B/px) fits the 256 MB Infinity Cache up to ~2.6 Mpx.  Beyond that the pair is swept
-    // band by band (sweeps_band_major), bands of at most ~150 MB; MAVFLOW_BANDS=1 with MAVFLOW_GROUP_FINE=0 gives the batched form.
+    // band by band (sweeps_band_major), bands of at most ~230 MB (measured at 3840x2160, 16 pairs: 3 bands 31.6 ms, 4 bands 32.4,
+    // 5 bands 34.3, 6 bands 35.0, batched sweep-major 35.4); MAVFLOW_BANDS=1 with MAVFLOW_GROUP_FINE=0 gives the batched form.
     if ((size_t)W * H * 80 > (size_t)200 << 20 && !getenv("MAVFLOW_GROUP_FINE")) {
         c->group_fine = 1;
         if (!getenv("MAVFLOW_BANDS")) {
-            c->bands = (int)(((size_t)W * H * 80 + ((size_t)150 << 20) - 1) / ((size_t)150 << 20));
+            c->bands = (int)(((size_t)W * H * 80 + ((size_t)230 << 20) - 1) / ((size_t)230 << 20));
             if (c->bands > 8) c->bands = 8;
         }
     }
@@ -626,7 +629,12 @@ static void layer_sweeps(mav_ctx* c, mav_ctx::WorkSet& w, hipStream_t st, int k,
     // The finest layer's ten sweeps re-read R0/R1 (and M or the flow): run them `group_fine` pairs at a time so that
     // one sub-group's working set stays resident in the 256 MB Infinity Cache between sweeps.  Coarse layers are
     // small: all g pairs per launch to fill the 256 CUs.
-    const int sub = (k == 0 && c->group_fine > 0 && c->group_fine < g) ? c->group_fine : g;
+    int sub = (k == 0 && c->group_fine > 0 && c->group_fine < g) ? c->group_fine : g;
+    if (k > 0 && c->coarse_cache_mb > 0) {        // coarse layers: as many pairs per launch as keep the sweeps' working set cache-sized
+        const size_t ws = (size_t)l.w * l.h * 80, cap = (size_t)c->coarse_cache_mb << 20;
+        const int fit = (int)(cap / (ws ? ws : 1));
+        if (fit < sub) sub = fit > 1 ? fit : 1;
+    }
     // Optional form ("recompute"): sweeps that rebuild M from (R0, R1, flow) on the fly -- no M arrays, no initial-M
     // kernel, 56 instead of 80 B/px of HBM traffic; the flow ping-pongs between the (otherwise unused) Ma / Mb buffers.
     // On MI355X at 1080p it is slower than the M-array form (27.6 vs 21.3 ms per 64 pairs: the limit is the per-CU
