@@ -321,16 +321,22 @@ def main():
         # corrected as the microarchitecture guide prescribes, committed under profiles/ with the hash of the sources they were
         # measured on.  Per launch, like `achieved`.  null unless the record matches this build, frame size, batch and schedule.
         traffic, traffic_source = None, None
-        tj = os.path.join(ROOT, "profiles", PROFILE_ROUND, "traffic.json")
-        if os.path.exists(tj):
-            rec_t = json.load(open(tj))
-            want = {"source_hash": source_hash(), "width": W, "height": H, "batch": B, "levels": args.levels, "launches": launches}
+        want = {"source_hash": source_hash(), "width": W, "height": H, "batch": B, "levels": args.levels, "launches": launches}
+        pdir = os.path.join(ROOT, "profiles", PROFILE_ROUND)
+        why = []
+        for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+            if not (name.startswith("traffic") and name.endswith(".json")):
+                continue
+            rec_t = json.load(open(os.path.join(pdir, name)))
             have = {k: rec_t.get(k) for k in want}
             if have == want:
                 traffic = int(rec_t["hbm_bytes_sweeps_per_step"] / max(launches, 1))
-                traffic_source = f"profiles/{PROFILE_ROUND}/traffic.json (rocprofv3 --pmc passes of this build and shape; not measured by this run)"
-            else:
-                traffic_source = f"profiles/{PROFILE_ROUND}/traffic.json does not describe this build/shape ({ {k: (have[k], want[k]) for k in want if have[k] != want[k]} }): null"
+                traffic_source = (f"profiles/{PROFILE_ROUND}/{name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build, shape and batch "
+                                  f"(memory-side bytes, Infinity-Cache hits included); not measured by this run")
+                break
+            why.append(f"{name}: " + ", ".join(f"{k} {have[k]} != {want[k]}" for k in want if have[k] != want[k]))
+        if traffic is None:
+            traffic_source = "no committed PMC record matches this build / shape (" + "; ".join(why) + "): null" if why else "no PMC record committed: null"
         roofline = {"bound": "hbm", "kernel": "k_blur_iter_fast (all sweep launches of a step)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                     "avg_launch_ms": round(ms / max(launches, 1), 4), "launches_per_step": launches,
