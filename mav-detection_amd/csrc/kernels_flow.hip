@@ -338,9 +338,9 @@ __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ I, si
                                                  float* __restrict__ R, size_t R_stride)
 {
     // grid-stride over the tiles in plain row-major order (a workgroup takes every gridDim.x-th tile: see grid_rows())
-    for (int tile = blockIdx.x; tile < tm.n_tiles; tile += gridDim.x) {
-    const int img_s = tile / tm.per_img;
-    const int tile_r = tile - img_s * tm.per_img;
+    for (int tile_i = blockIdx.x; tile_i < tm.n_tiles; tile_i += gridDim.x) {
+    const int img_s = tile_i / tm.per_img;
+    const int tile_r = tile_i - img_s * tm.per_img;
     const int tile_y = tile_r / tm.tiles_x, tile_x = tile_r - tile_y * tm.tiles_x;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n = N_T > 0 ? N_T : pc.n;
