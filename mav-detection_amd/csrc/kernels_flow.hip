@@ -63,23 +63,6 @@ static TileMap make_tile_map(int w, int h, int G, int tile_w, int tile_h, int ty
 }
 static inline unsigned tile_grid(const TileMap& tm) { return (unsigned)(((tm.n_tiles + 7) / 8) * 8); }
 
-// Streaming kernels walk their rows grid-stride: a launch of tens of thousands of workgroups whose waves live for a few
-// microseconds is bound by the rate at which waves can be launched, not by memory (measured on k_phi_mask: 0.55 -> 0.32 ms for
-// the same bytes when each workgroup takes 8 row blocks instead of 1).  y-blocks per launch are capped so that the whole grid
-// stays near `target` workgroups; env `knob` (blocks per workgroup) overrides for A/B runs.
-static unsigned grid_rows(unsigned blocks_y, unsigned blocks_xz, const char* knob, unsigned target = 4096)
-{
-    unsigned per = 0;
-    if (const char* e = getenv(knob)) per = (unsigned)atoi(e);
-    if (!per) {
-        const unsigned want = target / (blocks_xz ? blocks_xz : 1);
-        per = want ? (blocks_y + want - 1) / want : blocks_y;
-    }
-    if (per < 1) per = 1;
-    const unsigned gy = (blocks_y + per - 1) / per;
-    return gy ? gy : 1;
-}
-
 #ifdef MAV_STAMPS   // diagnostic build only (tools/phase_stamps.py): per-phase wave cycles of the sweep kernel, never in the product .so
 #define MAV_STAMP_WAVES (1 << 17)
 __device__ unsigned long long g_phase_cycles[MAV_STAMP_WAVES * 8];   // one row per wave slot of a launch: plain += (launches are serial)
@@ -131,8 +114,8 @@ __global__ __launch_bounds__(256) void k_blur_resize_h(const uint8_t* __restrict
                                                        BlurParams bp, float* __restrict__ tmp, size_t tmp_stride)
 {
     const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
-    if (dx >= w) return;
-    for (int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 4; y0 < H; y0 += 16 * gridDim.y) {     // grid-stride over blocks of 16 source rows
+    const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 4;
+    if (dx >= w || y0 >= H) return;
     const uint8_t* base = img + (size_t)blockIdx.z * img_stride;
     int s0; float f;
     resize_coord(dx, W, w, bp.scale_x, &s0, &f);
@@ -216,15 +199,14 @@ __global__ __launch_bounds__(256) void k_blur_resize_h(const uint8_t* __restrict
 #pragma unroll
     for (int k = 0; k < 4; k++)
         if (y0 + k < H) dst[(size_t)(y0 + k) * w] = b0[k] * a0 + b1[k] * f;
-    }
 }
 
 __global__ __launch_bounds__(256) void k_blur_resize_v(const float* __restrict__ tmp, size_t tmp_stride, int H, int w, int h,
                                                        BlurParams bp, float* __restrict__ out, size_t out_stride)
 {
     const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
-    if (dx >= w) return;
-    for (int dy = blockIdx.y * 4 + (threadIdx.x >> 6); dy < h; dy += 4 * gridDim.y) {             // grid-stride over blocks of 4 output rows
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= w || dy >= h) return;
     const float* src = tmp + (size_t)blockIdx.z * tmp_stride + dx;
     int s0; float f;
     resize_coord(dy, H, h, bp.scale_y, &s0, &f);
@@ -257,7 +239,6 @@ __global__ __launch_bounds__(256) void k_blur_resize_v(const float* __restrict__
         }
     }
     out[(size_t)blockIdx.z * out_stride + (size_t)dy * w + dx] = b0 * (1.f - f) + b1 * f;
-    }
 }
 
 // Layer 0 (scale 1, sigma 0 -> fixed kernel [1/4, 1/2, 1/4], BORDER_REFLECT_101): every product is exact in f32,
@@ -267,8 +248,8 @@ __global__ __launch_bounds__(256) void k_blur3_u8(const uint8_t* __restrict__ im
                                                   float* __restrict__ out, size_t out_stride)
 {
     const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-    if (x >= W) return;
-    for (int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 4; y0 < H; y0 += 16 * gridDim.y) {     // grid-stride over blocks of 16 rows
+    const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 4;
+    if (x >= W || y0 >= H) return;
     const uint8_t* src = img + (size_t)blockIdx.z * img_stride;
     float* dst = out + (size_t)blockIdx.z * out_stride;
     const int xl = x == 0 ? 1 : x - 1;                    // reflect101
@@ -307,7 +288,6 @@ __global__ __launch_bounds__(256) void k_blur3_u8(const uint8_t* __restrict__ im
         o.w = 0.5f * hrow[r + 1][3] + 0.25f * (hrow[r][3] + hrow[r + 2][3]);
         if (y0 + r < H) *(float4*)(dst + (size_t)(y0 + r) * W + x) = o;
     }
-    }
 }
 
 void launch_blur_resize(hipStream_t st, const uint8_t* img, size_t img_stride, int G, int W, int H, int w, int h,
@@ -315,13 +295,13 @@ void launch_blur_resize(hipStream_t st, const uint8_t* img, size_t img_stride, i
 {
     if (w == W && h == H && bp.fixed3 && W % 4 == 0 && W >= 8 && H >= 2 && img_stride % 4 == 0 && out_stride % 4 == 0 &&
         ((uintptr_t)img & 3) == 0 && ((uintptr_t)out & 15) == 0) {
-        dim3 grid((W / 4 + 63) / 64, grid_rows(((H + 3) / 4 + 3) / 4, ((W / 4 + 63) / 64) * G, "MAVFLOW_BLUR_YLOOP"), G);
+        dim3 grid((W / 4 + 63) / 64, ((H + 3) / 4 + 3) / 4, G);
         hipLaunchKernelGGL(k_blur3_u8, grid, dim3(256), 0, st, img, img_stride, W, H, out, out_stride);
         return;
     }
-    hipLaunchKernelGGL(k_blur_resize_h, dim3((w + 63) / 64, grid_rows(((H + 3) / 4 + 3) / 4, ((w + 63) / 64) * G, "MAVFLOW_BLUR_YLOOP"), G), dim3(256), 0, st, img, img_stride, W, H, w, bp,
+    hipLaunchKernelGGL(k_blur_resize_h, dim3((w + 63) / 64, ((H + 3) / 4 + 3) / 4, G), dim3(256), 0, st, img, img_stride, W, H, w, bp,
                        tmp, tmp_stride);
-    hipLaunchKernelGGL(k_blur_resize_v, dim3((w + 63) / 64, grid_rows((h + 3) / 4, ((w + 63) / 64) * G, "MAVFLOW_BLUR_YLOOP"), G), dim3(256), 0, st, (const float*)tmp, tmp_stride, H, w, h,
+    hipLaunchKernelGGL(k_blur_resize_v, dim3((w + 63) / 64, (h + 3) / 4, G), dim3(256), 0, st, (const float*)tmp, tmp_stride, H, w, h,
                        bp, out, out_stride);
 }
 
@@ -337,11 +317,8 @@ template <int N_T>
 __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ I, size_t I_stride, int w, int h, PolyCoef pc, TileMap tm,
                                                  float* __restrict__ R, size_t R_stride)
 {
-    // grid-stride over the tiles in plain row-major order (a workgroup takes every gridDim.x-th tile: see grid_rows())
-    for (int tile_i = blockIdx.x; tile_i < tm.n_tiles; tile_i += gridDim.x) {
-    const int img_s = tile_i / tm.per_img;
-    const int tile_r = tile_i - img_s * tm.per_img;
-    const int tile_y = tile_r / tm.tiles_x, tile_x = tile_r - tile_y * tm.tiles_x;
+    int img_s, tile_x, tile_y;
+    if (!tile_of_block(tm, &img_s, &tile_x, &tile_y)) return;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n = N_T > 0 ? N_T : pc.n;
     const int EX = PX + 2 * n, EY = PY + 2 * n;
@@ -421,8 +398,6 @@ __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ I, si
         dst[3 * npx + o] = b1 * pc.ig03 + b4 * pc.ig33;
         dst[4 * npx + o] = b6 * pc.ig55;
     }
-    __syncthreads();                                   // the LDS planes are re-used by the next tile
-    }
 }
 
 
@@ -434,7 +409,7 @@ void launch_polyexp(hipStream_t st, const float* I, size_t I_stride, int G, int 
     TileMap tm = make_tile_map(w, h, G, PX, PY);
     tm.xcd = 0;        // plain row-major order: measured 3 % faster here than the XCD-banded order (the halo re-reads that miss
                        // L2 hit the Infinity Cache, which all XCDs share; the kernel is VALU / write bound, not read bound)
-    const dim3 grid(grid_rows((unsigned)tm.n_tiles, 1, "MAVFLOW_POLY_LOOP", 8192));
+    const dim3 grid(tile_grid(tm));
     if (n == 8)
         hipLaunchKernelGGL(k_polyexp<8>, grid, dim3(256), lds, st, I, I_stride, w, h, pc, tm, R, R_stride);
     else if (n == 7)
@@ -551,26 +526,25 @@ __global__ __launch_bounds__(256) void k_update_matrices(const float* __restrict
                                                          int h, float* __restrict__ M, size_t M_stride)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
     const int s = blockIdx.z;
-    if (x >= w) return;
-    for (int y = blockIdx.y * 4 + (threadIdx.x >> 6); y < h; y += 4 * gridDim.y) {      // grid-stride over blocks of 4 rows
-        float dx = 0.f, dy = 0.f;
-        if (MODE == 1) {
-            const float2 f = upsample_flow(fsrc + (size_t)s * f_stride, pw, ph, mul, scale_x, scale_y, x, y);
-            dx = f.x; dy = f.y;
-        } else if (MODE == 2) {
-            const float2 f = *(const float2*)(fsrc + (size_t)s * f_stride + ((size_t)y * w + x) * 2);
-            dx = f.x; dy = f.y;
-        }
-        update_px(R0 + (size_t)s * R_stride, R1 + (size_t)s * R_stride, (size_t)w * h, w, h, x, y, dx, dy,
-                  M + (size_t)s * M_stride);
+    float dx = 0.f, dy = 0.f;
+    if (MODE == 1) {
+        const float2 f = upsample_flow(fsrc + (size_t)s * f_stride, pw, ph, mul, scale_x, scale_y, x, y);
+        dx = f.x; dy = f.y;
+    } else if (MODE == 2) {
+        const float2 f = *(const float2*)(fsrc + (size_t)s * f_stride + ((size_t)y * w + x) * 2);
+        dx = f.x; dy = f.y;
     }
+    update_px(R0 + (size_t)s * R_stride, R1 + (size_t)s * R_stride, (size_t)w * h, w, h, x, y, dx, dy,
+              M + (size_t)s * M_stride);
 }
 
 void launch_update_matrices(hipStream_t st, const float* R0, const float* R1, size_t R_stride, const float* flow_prev,
                             size_t fp_stride, int pw, int ph, float mul, int G, int w, int h, float* M, size_t M_stride)
 {
-    dim3 grid((w + 63) / 64, grid_rows((h + 3) / 4, ((w + 63) / 64) * G, "MAVFLOW_UPD_YLOOP"), G);
+    dim3 grid((w + 63) / 64, (h + 3) / 4, G);
     if (flow_prev)
         hipLaunchKernelGGL(k_update_matrices<1>, grid, dim3(256), 0, st, R0, R1, R_stride, flow_prev, fp_stride, pw, ph, mul,
                            (double)pw / w, (double)ph / h, w, h, M, M_stride);
@@ -582,7 +556,7 @@ void launch_update_matrices(hipStream_t st, const float* R0, const float* R1, si
 void launch_update_matrices_flow(hipStream_t st, const float* R0, const float* R1, size_t R_stride, const float* flow,
                                  size_t f_stride, int G, int w, int h, float* M, size_t M_stride)
 {
-    dim3 grid((w + 63) / 64, grid_rows((h + 3) / 4, ((w + 63) / 64) * G, "MAVFLOW_UPD_YLOOP"), G);
+    dim3 grid((w + 63) / 64, (h + 3) / 4, G);
     hipLaunchKernelGGL(k_update_matrices<2>, grid, dim3(256), 0, st, R0, R1, R_stride, flow, f_stride, 0, 0, 0.f, 0.0, 0.0,
                        w, h, M, M_stride);
 }
