@@ -668,15 +668,24 @@ static void layer_sweeps(mav_ctx* c, mav_ctx::WorkSet& w, hipStream_t st, int k,
         ProfScope ps(c, K_UPDATE, st);
         launch_update_matrices(st, w.R0, w.R1, 5 * n0, flow_prev, fc_stride, pw, ph, mul, g, l.w, l.h, w.Ma, 5 * n0);
     }
+    // Sub-groups are swept one after the other on one stream, so they all ping-pong M through the SAME two buffers (the first
+    // sub-group's slots): the M lines then stay hot in the Infinity Cache from pair to pair instead of leaving a dead 83 MB copy
+    // behind per pair.  Measured at 1080p, 64 pairs: 27.6 / 28.0 ms shared vs 28.2 / 28.6 ms with per-slot buffers (same box,
+    // alternating); MAVFLOW_SHARE_M=0 restores per-slot buffers.  (Going further -- building each pair's images and expansions
+    // right before its sweeps into one shared I / R0 / R1 as well, so that all 166 MB stay resident -- costs more in single-image
+    // blur / expansion launches, 3.0 + 1.7 vs 2.0 + 0.9 ms, than the warmer initial M and first sweep return: 28.4 vs 27.4 ms.)
+    static int share_m = -1;
+    if (share_m < 0) { const char* e = getenv("MAVFLOW_SHARE_M"); share_m = e ? atoi(e) : 1; }
     for (int s0 = 0; s0 < g; s0 += sub) {
         const int gs = g - s0 < sub ? g - s0 : sub;
+        const size_t m_off = (m_per_sub && share_m) ? 0 : (size_t)s0 * 5 * n0;
         if (m_per_sub) {
             ProfScope ps(c, K_UPDATE, st);
             launch_update_matrices(st, w.R0 + (size_t)s0 * 5 * n0, w.R1 + (size_t)s0 * 5 * n0, 5 * n0,
                                    flow_prev ? flow_prev + (size_t)s0 * fc_stride : nullptr, fc_stride, pw, ph, mul, gs, l.w, l.h,
-                                   w.Ma + (size_t)s0 * 5 * n0, 5 * n0);
+                                   w.Ma + m_off, 5 * n0);
         }
-        float *Min = w.Ma + (size_t)s0 * 5 * n0, *Mout = w.Mb + (size_t)s0 * 5 * n0;
+        float *Min = w.Ma + m_off, *Mout = w.Mb + m_off;
         const float *r0 = w.R0 + (size_t)s0 * 5 * n0, *r1 = w.R1 + (size_t)s0 * 5 * n0;
         float* fo = fdst + (size_t)s0 * fstride;
         const int T = blur_iter_tile_rows(l.h);
