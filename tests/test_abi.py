@@ -59,6 +59,10 @@ def test_bad_arguments_are_value_errors(mav):
         _lib.Context(64, 48, 1, fb)
     with pytest.raises(ValueError):
         _lib.Context(0, 48, 1)
+    fb = _lib.fb_defaults()
+    fb.winsize = 62                          # general sweep kernel: 5 x (32 + 62)^2 floats = 176 KB of LDS > the CU's 160 KB
+    with pytest.raises(ValueError, match="LDS"):
+        _lib.Context(640, 480, 1, fb)
 
 
 def test_product_never_imports_oracle():

@@ -279,3 +279,33 @@ def test_band_major_sweeps_are_bit_identical(mav, size):
             assert np.array_equal(c.farneback(prev[:1], nxt[:1]), one), bands
         c.set_option("group", 2)                       # a group of 2 + a group of 1
         assert np.array_equal(c.farneback(prev, nxt), ref)
+
+
+def test_pipeline_option_gives_the_same_flow(mav):
+    """Option "pipeline" (second work set + preparation stream, off by default because it measured slower) must stay correct:
+    three groups through two alternating work sets, twice, against the single-stream schedule."""
+    from mavflow import _lib
+    W, H, B = 640, 480, 5
+    prev, nxt = synth.make_batch(W, H, B, distinct=3)
+    with _lib.Context(W, H, B) as c:
+        c.set_option("group", 2)                        # groups of 2, 2, 1
+        ref = c.farneback(prev, nxt)
+        c.set_option("pipeline", 1)
+        for _ in range(2):
+            assert np.array_equal(c.farneback(prev, nxt), ref)
+        assert np.array_equal(c.farneback(prev[:2], nxt[:2]), ref[:2])       # a single group: nothing to pipeline
+        c.set_option("pipeline", 0)
+        assert np.array_equal(c.farneback(prev, nxt), ref)
+
+
+def test_winsize_beyond_the_fast_kernel(mav, fb_oracle):
+    """winsize 20 takes the general sweep kernel with 53 KB... up to 160 KB of dynamic LDS (granted per device in mav_create)."""
+    from mavflow import _lib
+    from oracle import fb_oracle as fbo
+    W, H = 320, 240
+    f0, f1, _ = synth.make_pair(W, H, 6)
+    fb = _lib.fb_defaults()
+    fb.winsize, fb.iterations = 40, 2                   # 5 x (32 + 40)^2 floats = 104 KB > the 64 KB default limit
+    with _lib.Context(W, H, 1, fb) as c:
+        got = c.farneback(f0, f1)[0]
+    _check_flow(got, fb_oracle.calc(f0, f1, fbo.Params(0.4, 1, 40, 2, 8, 1.2, 0)), "winsize 40")
