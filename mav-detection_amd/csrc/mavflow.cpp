@@ -1304,8 +1304,10 @@ extern "C" int mav_last_masks_tpr_fpr(mav_ctx* c, const uint8_t* gt, int mask_va
     HIPCHK(hipSetDevice(c->device));
     // the ground truth goes into the NEXT free staging block: the previous call's blocks (its masks among them) stay untouched
     const uint8_t *mf = c->last_mf, *md = c->last_md;
+    const size_t mark = c->scratch_next;
     DevBuf dg;
     CHK(dg.upload(c, gt, c->n0 * batch));
+    c->scratch_next = mark;          // the call is synchronous: its block is free again on return, a repeated call re-uses it
     for (int k = 0; k < 2; k++) {
         int64_t* out = k == 0 ? counts_fixed : counts_dyn;
         if (!out) continue;

@@ -200,7 +200,7 @@ class _PinnedPool:
         # the finalizer hangs on the ctypes object that OWNS the memory in numpy's eyes: every array or view derived from it
         # (numpy collapses view chains onto the owner) keeps it alive, so the block returns only when the last of them is gone
         owner = (C.c_uint8 * nbytes).from_address(ptr)
-        weakref.finalize(owner, self._give, nbytes, ptr)
+        weakref.finalize(owner, self._give, nbytes, ptr).atexit = False      # at interpreter exit the OS reclaims; no HIP calls then
         return np.ctypeslib.as_array(owner).view(dtype)[:int(np.prod(shape))].reshape(shape)
 
     def _give(self, nbytes, ptr):
