@@ -78,13 +78,18 @@ int mav_device_count(void);       /* <= 0 when no GPU is visible */
  * from (R0, R1, flow) on the fly instead of storing it (default 0); "pipeline" = 1: a second work set and stream prepare
  * group i + 1 (pyramid, expansions) while group i's finest-layer sweeps run (default 0: measured slower); "bands" = J in [1, 8]: the
  * finest layer's sweeps of a pair run band by band over J skewed horizontal bands (default: 1 up to ~2.6 Mpx, above that as many
- * bands as keep one band's working set inside the Infinity Cache). MAV_ERR_ARG for unknown names. */
+ * bands as keep one band's working set inside the Infinity Cache); "share_frames" = 0: treat a frame sequence (see mav_farneback)
+ * as independent pairs (default 1). MAV_ERR_ARG for unknown names. */
 int mav_set_option(mav_ctx*, const char* name, long value);
 int mav_num_layers(const mav_ctx*);
 int mav_layer_dims(const mav_ctx*, int k, int* w, int* h, int* ksize, double* sigma);
 
 /* ---- host-pointer entry points (synchronous) ----------------------------------------------------------- */
-/* cv2.calcOpticalFlowFarneback(prev, next, None, *fb)   [src/farneback.py:76-80] for `batch` pairs. */
+/* cv2.calcOpticalFlowFarneback(prev, next, None, *fb)   [src/farneback.py:76-80] for `batch` pairs.
+ * FRAME SEQUENCES: the reference calls this with next = the frame after prev and keeps `prevgray` for the following call, i.e. a
+ * video of n + 1 frames is n pairs whose inner frames each appear twice.  When the two batches are views of ONE run of batch + 1
+ * frames -- next == prev + W*H, in every entry point that takes prev / next, host or device pointers -- the library uploads the run
+ * once and blurs / expands every frame once per group instead of twice.  The flow is bit-identical to the two-batch form. */
 int mav_farneback(mav_ctx*, const uint8_t* prev, const uint8_t* next, int batch, float* flow);
 /* Detector.derotate [src/detector.py:70-117]: omega = angular difference / dt, (batch,3); dt (batch). */
 int mav_derotate(mav_ctx*, const float* flow, const double* omega, const double* dt, int batch, double* flow_out);

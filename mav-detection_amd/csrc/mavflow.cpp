@@ -201,10 +201,15 @@ struct mav_ctx {
     struct WorkSet {
         float *Htmp = nullptr;       // scratch of the separable blur+resize: group x H x (widest coarse layer)
         float *I = nullptr, *R0 = nullptr, *R1 = nullptr, *Ma = nullptr, *Mb = nullptr, *fc[2] = {nullptr, nullptr};
+        // R0 and R1 are the two halves of ONE allocation (R1 = R0 + 5 n0 group).  r0 / r1 = where the expansions of the layer in
+        // work lie (layer_expansions): R0 / R1 for independent pairs; for a frame SEQUENCE (next = prev + one frame) the group's
+        // g + 1 frames are expanded once into slots 0 .. g of that allocation and pair s reads slots s and s + 1: r1 = R0 + 5 n0.
+        const float *r0 = nullptr, *r1 = nullptr;
     } ws[2];
     int nsets = 1;
     bool pipeline = false;           // option "pipeline" (off: measured 2 % slower): prepare group i + 1 while group i sweeps
     int bands = 1;                   // option "bands": the finest layer's sweeps in band-major order over this many skewed bands
+    bool share_frames = true;        // option "share_frames": expand a frame once when next == prev + one frame (a frame sequence)
     int coarse_cache_mb = 220;       // coarse layers: pairs per launch capped so that the sweeps' working set stays below this (0 = no cap)
     hipStream_t prep_stream = nullptr;
     hipEvent_t prep_done[2] = {nullptr, nullptr}, fine_done[2] = {nullptr, nullptr}, call_begin = nullptr;
@@ -258,13 +263,14 @@ static int alloc_group(mav_ctx* c, int group)
 {
     const int nsets = (c->pipeline && c->max_batch > group) ? 2 : 1;
     const size_t g = (size_t)group, nc = 2 * (c->n1 ? c->n1 : 1);
-    const size_t elems[8] = {c->n0 * g, 5 * c->n0 * g, 5 * c->n0 * g, 5 * c->n0 * g, 5 * c->n0 * g, nc * g, nc * g, c->htmp_stride * g};
-    float* fresh[2][8] = {{nullptr}, {nullptr}};
+    // I and Htmp hold one frame more than the group: a frame sequence of g pairs has g + 1 frames.  R = R0 | R1 in one piece.
+    const size_t elems[7] = {c->n0 * (g + 1), 10 * c->n0 * g, 5 * c->n0 * g, 5 * c->n0 * g, nc * g, nc * g, c->htmp_stride * (g + 1)};
+    float* fresh[2][7] = {{nullptr}, {nullptr}};
     for (int s = 0; s < nsets; s++)
-        for (int i = 0; i < 8; i++) {
+        for (int i = 0; i < 7; i++) {
             const hipError_t e = hipMalloc(&fresh[s][i], sizeof(float) * elems[i]);
             if (e != hipSuccess) {
-                for (int t = 0; t <= s; t++) for (int j = 0; j < 8; j++) if (fresh[t][j]) hipFree(fresh[t][j]);
+                for (int t = 0; t <= s; t++) for (int j = 0; j < 7; j++) if (fresh[t][j]) hipFree(fresh[t][j]);
                 (void)hipGetLastError();
                 return fail(e == hipErrorOutOfMemory ? MAV_ERR_OOM : MAV_ERR_HIP, "workspace for group %d (%zu bytes for buffer %d of set %d): %s",
                             group, sizeof(float) * elems[i], i, s, hipGetErrorString(e));
@@ -272,8 +278,10 @@ static int alloc_group(mav_ctx* c, int group)
         }
     for (int s = 0; s < 2; s++) {
         mav_ctx::WorkSet& w = c->ws[s];
-        float** bufs[8] = {&w.I, &w.R0, &w.R1, &w.Ma, &w.Mb, &w.fc[0], &w.fc[1], &w.Htmp};
-        for (int i = 0; i < 8; i++) { if (*bufs[i]) hipFree(*bufs[i]); *bufs[i] = s < nsets ? fresh[s][i] : nullptr; }
+        float** bufs[7] = {&w.I, &w.R0, &w.Ma, &w.Mb, &w.fc[0], &w.fc[1], &w.Htmp};
+        for (int i = 0; i < 7; i++) { if (*bufs[i]) hipFree(*bufs[i]); *bufs[i] = s < nsets ? fresh[s][i] : nullptr; }
+        w.R1 = w.R0 ? w.R0 + 5 * c->n0 * g : nullptr;
+        w.r0 = w.R0; w.r1 = w.R1;
     }
     c->group = group;
     c->nsets = nsets;
@@ -288,7 +296,7 @@ extern "C" int mav_destroy(mav_ctx* c)
     for (auto& l : c->layers) free_layer(l);
     if (c->prep_stream) hipStreamSynchronize(c->prep_stream);
     for (auto& w : c->ws) {
-        void* wb[] = {w.I, w.R0, w.R1, w.Ma, w.Mb, w.fc[0], w.fc[1], w.Htmp};
+        void* wb[] = {w.I, w.R0, w.Ma, w.Mb, w.fc[0], w.fc[1], w.Htmp};      // R1 is the second half of R0's allocation
         for (void* b : wb) if (b) hipFree(b);
     }
     void* bufs[] = {c->flow_ws, c->foe_sc.cand, c->foe_sc.count,
@@ -438,6 +446,7 @@ extern "C" int mav_set_option(mav_ctx* c, const char* name, long value)
         return rc;
     }
     if (!strcmp(name, "recompute")) { c->use_rc = value != 0; return MAV_OK; }
+    if (!strcmp(name, "share_frames")) { c->share_frames = value != 0; return MAV_OK; }
     if (!strcmp(name, "group_fine")) {
         if (value < 0) return fail(MAV_ERR_ARG, "group_fine must be >= 0 (0 = same as group)");
         c->group_fine = (int)value;
@@ -651,8 +660,8 @@ static void layer_sweeps(mav_ctx* c, mav_ctx::WorkSet& w, hipStream_t st, int k,
                 const size_t fin_stride = it > 0 ? 5 * n0 : fc_stride;
                 float* fo = last ? fdst + (size_t)s0 * fstride : buf[it & 1];
                 ProfScope ps(c, k == 0 ? K_ITER : K_ITER_COARSE, st);
-                if (!launch_sweep_rc(st, mode, fin, fin_stride, pw, ph, mul, w.R0 + (size_t)s0 * 5 * n0,
-                                     w.R1 + (size_t)s0 * 5 * n0, 5 * n0, gs, l.w, l.h, c->fb.winsize, fo, last ? fstride : 5 * n0)) {
+                if (!launch_sweep_rc(st, mode, fin, fin_stride, pw, ph, mul, w.r0 + (size_t)s0 * 5 * n0,
+                                     w.r1 + (size_t)s0 * 5 * n0, 5 * n0, gs, l.w, l.h, c->fb.winsize, fo, last ? fstride : 5 * n0)) {
                     rc_ok = false;      // (only possible on the very first launch: alignment) -> M-array form below
                     break;
                 }
@@ -666,7 +675,7 @@ static void layer_sweeps(mav_ctx* c, mav_ctx::WorkSet& w, hipStream_t st, int k,
     const bool m_per_sub = sub < g;
     if (!m_per_sub) {
         ProfScope ps(c, K_UPDATE, st);
-        launch_update_matrices(st, w.R0, w.R1, 5 * n0, flow_prev, fc_stride, pw, ph, mul, g, l.w, l.h, w.Ma, 5 * n0);
+        launch_update_matrices(st, w.r0, w.r1, 5 * n0, flow_prev, fc_stride, pw, ph, mul, g, l.w, l.h, w.Ma, 5 * n0);
     }
     // Sub-groups are swept one after the other on one stream, so they all ping-pong M through the SAME two buffers (the first
     // sub-group's slots): the M lines then stay hot in the Infinity Cache from pair to pair instead of leaving a dead 83 MB copy
@@ -681,12 +690,12 @@ static void layer_sweeps(mav_ctx* c, mav_ctx::WorkSet& w, hipStream_t st, int k,
         const size_t m_off = (m_per_sub && share_m) ? 0 : (size_t)s0 * 5 * n0;
         if (m_per_sub) {
             ProfScope ps(c, K_UPDATE, st);
-            launch_update_matrices(st, w.R0 + (size_t)s0 * 5 * n0, w.R1 + (size_t)s0 * 5 * n0, 5 * n0,
+            launch_update_matrices(st, w.r0 + (size_t)s0 * 5 * n0, w.r1 + (size_t)s0 * 5 * n0, 5 * n0,
                                    flow_prev ? flow_prev + (size_t)s0 * fc_stride : nullptr, fc_stride, pw, ph, mul, gs, l.w, l.h,
                                    w.Ma + m_off, 5 * n0);
         }
         float *Min = w.Ma + m_off, *Mout = w.Mb + m_off;
-        const float *r0 = w.R0 + (size_t)s0 * 5 * n0, *r1 = w.R1 + (size_t)s0 * 5 * n0;
+        const float *r0 = w.r0 + (size_t)s0 * 5 * n0, *r1 = w.r1 + (size_t)s0 * 5 * n0;
         float* fo = fdst + (size_t)s0 * fstride;
         const int T = blur_iter_tile_rows(l.h);
         // bands (finest layer, one pair per launch): at least iterations + 2 tile rows each, so that the skewed band edges never
@@ -707,11 +716,20 @@ static void layer_sweeps(mav_ctx* c, mav_ctx::WorkSet& w, hipStream_t st, int k,
     }
 }
 
-// Layer images and polynomial expansions of both frames at layer k (g slots of set w, stream st) -> w.R0, w.R1.
-static void layer_expansions(mav_ctx* c, mav_ctx::WorkSet& w, hipStream_t st, int k, const uint8_t* prev, const uint8_t* next, int g)
+// Layer images and polynomial expansions of both frames at layer k (g slots of set w, stream st) -> w.r0, w.r1.
+// seq: `prev` is a run of g + 1 consecutive frames and pair s = (frame s, frame s + 1): every frame is blurred and expanded ONCE.
+static void layer_expansions(mav_ctx* c, mav_ctx::WorkSet& w, hipStream_t st, int k, const uint8_t* prev, const uint8_t* next, int g, bool seq)
 {
     const size_t n0 = c->n0;
     const Layer& l = c->layers[k];
+    if (seq) {
+        { ProfScope ps(c, K_BLUR_RESIZE, st);
+          launch_blur_resize(st, prev, n0, g + 1, c->W, c->H, l.w, l.h, blur_of(c, l), w.Htmp, c->htmp_stride, w.I, n0); }
+        { ProfScope ps(c, K_POLYEXP, st);
+          launch_polyexp(st, w.I, n0, g + 1, l.w, l.h, c->pc, w.R0, 5 * n0); }
+        w.r0 = w.R0; w.r1 = w.R0 + 5 * n0;
+        return;
+    }
     const uint8_t* img[2] = {prev, next};
     float* R[2] = {w.R0, w.R1};
     for (int i = 0; i < 2; i++) {
@@ -720,22 +738,23 @@ static void layer_expansions(mav_ctx* c, mav_ctx::WorkSet& w, hipStream_t st, in
         { ProfScope ps(c, K_POLYEXP, st);
           launch_polyexp(st, w.I, n0, g, l.w, l.h, c->pc, R[i], 5 * n0); }
     }
+    w.r0 = w.R0; w.r1 = w.R1;
 }
 
 // PREPARATION of a group: every coarse layer completely (top layer first), then the finest layer's images and expansions.
-// Leaves in w: R0 / R1 of layer 0 and, when there is a coarse layer, layer 1's flow in w.fc[1].
-static void prep_group(mav_ctx* c, mav_ctx::WorkSet& w, hipStream_t st, const uint8_t* prev, const uint8_t* next, int g)
+// Leaves in w: r0 / r1 of layer 0 and, when there is a coarse layer, layer 1's flow in w.fc[1].
+static void prep_group(mav_ctx* c, mav_ctx::WorkSet& w, hipStream_t st, const uint8_t* prev, const uint8_t* next, int g, bool seq)
 {
     const int L = (int)c->layers.size();
     const size_t fc_stride = 2 * (c->n1 ? c->n1 : 1);
     const float* flow_prev = nullptr;
     int pw = 0, ph = 0;
     for (int k = L - 1; k >= 1; k--) {
-        layer_expansions(c, w, st, k, prev, next, g);
+        layer_expansions(c, w, st, k, prev, next, g, seq);
         layer_sweeps(c, w, st, k, g, flow_prev, fc_stride, pw, ph, w.fc[k & 1], fc_stride);
         flow_prev = w.fc[k & 1]; pw = c->layers[k].w; ph = c->layers[k].h;
     }
-    layer_expansions(c, w, st, 0, prev, next, g);
+    layer_expansions(c, w, st, 0, prev, next, g, seq);
 }
 // SWEEPS of a group: the finest layer's initial M and iterations -> flow_out.
 static void fine_group(mav_ctx* c, mav_ctx::WorkSet& w, hipStream_t st, int g, float* flow_out)
@@ -760,6 +779,11 @@ extern "C" int mav_farneback_dev(mav_ctx* c, const uint8_t* prev, const uint8_t*
     // a set is prepared only after the sweeps that last used it (fine_done), swept only after its preparation (prep_done), and
     // the preparation stream starts behind everything already enqueued on the compute stream (call_begin).  Per-kernel
     // profiling runs everything on the compute stream so that each launch is timed alone.
+    // A frame SEQUENCE -- the caller's two batches are views of one run of batch + 1 consecutive frames, next = prev + one frame,
+    // which is how a video goes through the reference's loop (src/farneback.py:76-80 with prevgray = the last call's frame) -- has
+    // every inner frame in two pairs.  Each group then blurs and expands its g + 1 frames once instead of 2 g (same arithmetic per
+    // frame: the flow is bit-identical to the two-batch form; tests/test_gpu_flow.py).  Option "share_frames" = 0 switches it off.
+    const bool seq = c->share_frames && next == prev + c->n0;
     const bool pipe = c->pipeline && c->nsets == 2 && batch > c->group && !c->profiling;
     if (pipe) {
         HIPCHK(hipEventRecord(c->call_begin, c->stream));
@@ -772,7 +796,7 @@ extern "C" int mav_farneback_dev(mav_ctx* c, const uint8_t* prev, const uint8_t*
         mav_ctx::WorkSet& w = c->ws[set];
         const hipStream_t ps = pipe ? c->prep_stream : c->stream;
         if (pipe && gi >= 2) HIPCHK(hipStreamWaitEvent(ps, c->fine_done[set], 0));
-        prep_group(c, w, ps, prev + (size_t)g0 * c->n0, next + (size_t)g0 * c->n0, g);
+        prep_group(c, w, ps, prev + (size_t)g0 * c->n0, next + (size_t)g0 * c->n0, g, seq);
         if (pipe) {
             HIPCHK(hipEventRecord(c->prep_done[set], ps));
             HIPCHK(hipStreamWaitEvent(c->stream, c->prep_done[set], 0));
@@ -920,6 +944,22 @@ struct DevBuf {
     }
     template <typename T> T* as() { return (T*)p; }
 };
+// The two frame batches of a host-pointer call -> device.  When the caller's batches are views of one run of batch + 1 frames
+// (next == prev + one frame) the run crosses PCIe once and keeps that layout on the device, which mav_farneback_dev recognises.
+static int upload_frames(mav_ctx* c, const uint8_t* prev, const uint8_t* next, int batch, DevBuf& dp, DevBuf& dn, const uint8_t** dprev,
+                         const uint8_t** dnext)
+{
+    const size_t n = c->n0 * batch;
+    if (next == prev + c->n0) {
+        CHK(dp.upload(c, prev, n + c->n0));
+        CHK(dn.alloc(c, 1));                              // keeps the staging slots of the two call forms aligned
+        *dprev = dp.as<uint8_t>(); *dnext = dp.as<uint8_t>() + c->n0;
+        return MAV_OK;
+    }
+    CHK(dp.upload(c, prev, n)); CHK(dn.upload(c, next, n));
+    *dprev = dp.as<uint8_t>(); *dnext = dn.as<uint8_t>();
+    return MAV_OK;
+}
 static int download(mav_ctx* c, void* dst, const void* src, size_t bytes)
 {
     HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
@@ -941,8 +981,9 @@ extern "C" int mav_farneback(mav_ctx* c, const uint8_t* prev, const uint8_t* nex
     if (!prev || !next || !flow) return fail(MAV_ERR_ARG, "mav_farneback: NULL argument");
     const size_t n = c->n0 * batch;
     DevBuf dp, dn, df;
-    CHK(dp.upload(c, prev, n)); CHK(dn.upload(c, next, n)); CHK(df.alloc(c, n * 2 * sizeof(float)));
-    CHK(mav_farneback_dev(c, dp.as<uint8_t>(), dn.as<uint8_t>(), batch, df.as<float>()));
+    const uint8_t *dprev, *dnext;
+    CHK(upload_frames(c, prev, next, batch, dp, dn, &dprev, &dnext)); CHK(df.alloc(c, n * 2 * sizeof(float)));
+    CHK(mav_farneback_dev(c, dprev, dnext, batch, df.as<float>()));
     CHK(download(c, flow, df.p, n * 2 * sizeof(float)));
     return mav_sync(c);
 }
@@ -1272,8 +1313,9 @@ static int process_host(mav_ctx* c, const char* fn, const uint8_t* prev, const u
     if (f.n_pairs < 1 || f.n_pairs > 4096) return fail(MAV_ERR_ARG, "n_pairs %d outside [1, 4096]", f.n_pairs);
     const size_t n = c->n0 * batch;
     DevBuf dp, dn, ds, dflow, dres, dmf, dmd, dsky, dom, ddt, df0, dphi;      // the always-present buffers take the first blocks
+    const uint8_t *dprev = nullptr, *dnext = nullptr;
     if (flow_in) CHK(dflow.upload(c, flow_in, n * 2 * sizeof(float)));
-    else { CHK(dp.upload(c, prev, n)); CHK(dn.upload(c, next, n)); CHK(dflow.alloc(c, n * 2 * sizeof(float))); }
+    else { CHK(upload_frames(c, prev, next, batch, dp, dn, &dprev, &dnext)); CHK(dflow.alloc(c, n * 2 * sizeof(float))); }
     CHK(ds.upload(c, samples, sizeof(uint32_t) * 4 * (size_t)f.n_pairs * batch));
     CHK(dres.alloc(c, sizeof(mav_result) * batch));
     if (mask_fixed) CHK(dmf.alloc(c, n));
@@ -1283,7 +1325,7 @@ static int process_host(mav_ctx* c, const char* fn, const uint8_t* prev, const u
     if (omega && dt) CHK(ddt.upload(c, dt, sizeof(double) * batch));
     if (frame0) CHK(df0.upload(c, frame0, batch));
     if (phi) CHK(dphi.alloc(c, n * sizeof(double)));
-    if (!flow_in) CHK(mav_farneback_dev(c, dp.as<uint8_t>(), dn.as<uint8_t>(), batch, dflow.as<float>()));
+    if (!flow_in) CHK(mav_farneback_dev(c, dprev, dnext, batch, dflow.as<float>()));
     CHK(mav_detect_dev(c, dflow.as<float>(), ds.as<uint32_t>(), dom.as<double>(), ddt.as<double>(), df0.as<uint8_t>(),
                        dsky.as<uint8_t>(), batch, &f, tp, dphi.as<double>(), dmf.as<uint8_t>(), dmd.as<uint8_t>(), dres.as<mav_result>()));
     c->last_mf = dmf.as<uint8_t>(); c->last_md = dmd.as<uint8_t>(); c->last_mask_batch = batch;

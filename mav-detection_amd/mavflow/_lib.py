@@ -325,6 +325,16 @@ class Context:
         check(self.lib.mav_farneback(self.h, _ptr(prev), _ptr(nxt), B, _ptr(flow)))
         return flow
 
+    def farneback_sequence(self, frames) -> np.ndarray:
+        """Flow of every consecutive pair of a run of frames (n + 1, H, W) u8 -> (n, H, W, 2) float32.  The two batches handed to
+        the library are views of the one array (next = prev + one frame), which it recognises: the run is uploaded once and every
+        frame is blurred and expanded once instead of twice.  Same flow, bit for bit, as farneback(frames[:-1], frames[1:]) on
+        separate copies."""
+        frames = self._imgs(frames, "frames")
+        if frames.shape[0] < 2:
+            raise ValueError("a sequence needs at least two frames")
+        return self.farneback(frames[:-1], frames[1:])
+
     def derotate(self, flow, omega, dt) -> np.ndarray:
         flow = np.asarray(flow, np.float32)
         flow = flow[None] if flow.ndim == 3 else flow

@@ -34,14 +34,21 @@ class FloFlowProvider:
 
 
 class FarnebackFlowProvider:
-    """get_gray(i) -> u8 (H, W) frame i (BGR frames are converted on the GPU).  One context, one pair per call, exactly the call
-    shape of src/farneback.py:76-80; `cache` keeps the previous frame's upload-side conversion."""
+    """get_gray(i) -> u8 (H, W) frame i (BGR frames are converted on the GPU).  window = 1: one pair per call, exactly the call
+    shape of src/farneback.py:76-80.  window = n > 1 (with n_frames = the length of the video): a call for flow i that is not in
+    the cache computes flows i .. i + n - 1 in one go from the n + 1 frames i .. i + n as a frame SEQUENCE -- one upload, every
+    frame blurred and expanded once (Context.farneback_sequence) -- so the reference's frame-by-frame loop runs batched without
+    changing; the fields are bit-identical to the one-pair calls."""
 
     def __init__(self, get_gray: Callable[[int], np.ndarray], width: int, height: int, img_path: Optional[str] = None,
-                 write_flo: bool = False) -> None:
+                 write_flo: bool = False, window: int = 1, n_frames: Optional[int] = None) -> None:
         from . import _lib
         self.get_gray, self.img_path, self.write_flo = get_gray, img_path, write_flo
-        self.ctx = _lib.Context(width, height, 1)
+        if window < 1 or (window > 1 and n_frames is None):
+            raise ValueError("window must be >= 1, and a window > 1 needs n_frames")
+        self.window, self.n_frames = int(window), n_frames
+        self.ctx = _lib.Context(width, height, self.window)
+        self._cache: dict = {}
         if write_flo and not img_path:
             raise ValueError("write_flo needs img_path")
 
@@ -49,8 +56,17 @@ class FarnebackFlowProvider:
         f = np.asarray(self.get_gray(i))
         return self.ctx.bgr2gray(f)[0] if f.ndim == 3 else np.ascontiguousarray(f, np.uint8)
 
+    def _compute(self, i: int) -> np.ndarray:
+        if self.window == 1:
+            return self.ctx.farneback(self._gray(i), self._gray(i + 1))[0]
+        if i not in self._cache:
+            n = max(1, min(self.window, self.n_frames - 1 - i))
+            flows = self.ctx.farneback_sequence(np.stack([self._gray(j) for j in range(i, i + n + 1)]))
+            self._cache = {i + k: flows[k] for k in range(n)}         # views of one (pinned) result block
+        return self._cache[i]
+
     def get_flow_uv(self, i: int) -> np.ndarray:
-        flow = self.ctx.farneback(self._gray(i), self._gray(i + 1))[0]
+        flow = self._compute(i)
         if self.write_flo:
             path = flo_path(self.img_path, i)
             os.makedirs(os.path.dirname(path), exist_ok=True)

@@ -90,6 +90,22 @@ def make_batch(W: int, H: int, batch: int, distinct: int = 4):
     return prev, nxt
 
 
+def make_sequence(W: int, H: int, n_frames: int, seed: int = 0, k: float = 0.004) -> np.ndarray:
+    """A synthetic VIDEO: n_frames u8 (n, H, W) of one texture under a growing radial zoom about (0.55 W, 0.45 H), frame j an
+    exact warp of the texture by j * k * (x - cx, y - cy).  Pair i of the sequence is (frame i, frame i + 1): every inner frame
+    belongs to two pairs, which is how a video runs through the reference's loop (src/farneback.py:76-80)."""
+    rng = np.random.default_rng(20240 + 1000 + seed)
+    fx, fy, amp, phase = _texture_params(rng)
+    x = np.arange(W, dtype=np.float64)
+    y = np.arange(H, dtype=np.float64)
+    A = 119.5 / np.abs(_eval_separable(x, y, fx, fy, amp, phase)).max()
+    out = np.empty((n_frames, H, W), np.uint8)
+    for j in range(n_frames):
+        t = _eval_separable(x - j * k * (x - 0.55 * W), y - j * k * (y - 0.45 * H), fx, fy, amp, phase)
+        out[j] = np.clip(np.rint(127.5 + A * t), 0, 255).astype(np.uint8)
+    return out
+
+
 def foe_samples(W: int, H: int, pair_index: int = 0, n_pairs: int = 1000) -> np.ndarray:
     """(2N, 2) uint32 (row, col) sample coordinates drawn exactly as focus_of_expansion.py:70-71 does."""
     state = np.random.get_state()

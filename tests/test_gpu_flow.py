@@ -309,3 +309,40 @@ def test_winsize_beyond_the_fast_kernel(mav, fb_oracle):
     with _lib.Context(W, H, 1, fb) as c:
         got = c.farneback(f0, f1)[0]
     _check_flow(got, fb_oracle.calc(f0, f1, fbo.Params(0.4, 1, 40, 2, 8, 1.2, 0)), "winsize 40")
+
+
+def test_frame_sequence_shares_expansions_bit_identical(mav):
+    """A video (n + 1 frames, pair i = frames i, i + 1: src/farneback.py:76-80 with prevgray carried over) handed over as two views of
+    ONE array is recognised (next == prev + one frame): uploaded once, every frame blurred and expanded once per group.  The flow must
+    equal the two-batch form on separate copies bit for bit -- host pointers, device pointers, the fused chain, groups of 2 + 2 + 1,
+    a single pair -- and option share_frames = 0 must change nothing but the work done."""
+    from mavflow import _lib
+    W, H, B = 640, 480, 5
+    frames = synth.make_sequence(W, H, B + 1)
+    assert (frames[0] != frames[1]).mean() > 0.5
+    prev, nxt = frames[:-1].copy(), frames[1:].copy()           # separate arrays: no aliasing to recognise
+    smp = np.stack([synth.foe_samples(W, H, b) for b in range(B)])
+    with _lib.Context(W, H, B) as c:
+        c.set_option("group", 2)
+        ref = c.farneback(prev, nxt)
+        assert np.array_equal(c.farneback_sequence(frames), ref)
+        assert np.array_equal(c.farneback(frames[:-1], frames[1:]), ref)
+        assert np.array_equal(c.farneback_sequence(frames[:2]), ref[:1])                 # one pair: two frames in a group of one
+        assert np.array_equal(c.farneback_sequence(frames[1:5]), ref[1:4])
+        # device pointers: one buffer holding the run
+        d = c.alloc(frames.nbytes); d.upload(frames)
+        out = c.alloc(ref.nbytes)
+        c.farneback_dev(d.ptr, d.ptr + W * H, B, out.ptr)
+        c.sync()
+        assert np.array_equal(out.download(np.float32, ref.shape), ref)
+        # the fused chain
+        a = c.process_batch(prev, nxt, smp)
+        b = c.process_batch(frames[:-1], frames[1:], smp)
+        for key in ("flow", "mask_fixed", "mask_dyn"):
+            assert np.array_equal(a[key], b[key]), key
+        assert a["results"].tobytes() == b["results"].tobytes()
+        c.set_option("share_frames", 0)
+        assert np.array_equal(c.farneback_sequence(frames), ref)
+        c.set_option("share_frames", 1)
+        c.set_option("group", 5)                                                            # one group of five pairs = six frames
+        assert np.array_equal(c.farneback_sequence(frames), ref)

@@ -174,6 +174,18 @@ def test_farneback_flow_provider_fills_the_reference_flow_seam(mav, tmp_path, fb
     prov = FarnebackFlowProvider(lambda i: np.repeat(frames[i][..., None], 3, axis=2), W, H)
     assert np.array_equal(prov.get_flow_uv(0), f0)
     prov.release()
+    # window > 1: the frame-by-frame loop runs batched as frame sequences (every frame expanded once), same fields bit for bit
+    video = synth.make_sequence(W, H, 8)
+    one = FarnebackFlowProvider(lambda i: video[i], W, H)
+    calls = []
+    win = FarnebackFlowProvider(lambda i: (calls.append(i), video[i])[1], W, H, window=3, n_frames=len(video))
+    for i in range(len(video) - 1):
+        assert np.array_equal(win.get_flow_uv(i), one.get_flow_uv(i)), i
+    assert calls == [0, 1, 2, 3, 3, 4, 5, 6, 6, 7]               # windows of 3, 3 and 1 pairs: 4 + 4 + 2 frames fetched
+    assert np.array_equal(win.get_flow_uv(5), one.get_flow_uv(5))   # a random access recomputes its window
+    one.release(); win.release()
+    with pytest.raises(ValueError):
+        FarnebackFlowProvider(lambda i: video[i], W, H, window=4)
 
 
 def test_pyramid_generator_yields_every_level(mav):
