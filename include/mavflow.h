@@ -73,7 +73,7 @@ int mav_create(mav_ctx** out, int device, int W, int H, int max_batch, const mav
 int mav_destroy(mav_ctx*);
 const char* mav_last_error(void); /* thread-local, never NULL */
 int mav_device_count(void);       /* <= 0 when no GPU is visible */
-/* Tuning: "group" = pairs per launch (>= 1, default 8); "group_fine" = pairs per launch for the finest layer's sweeps
+/* Tuning: "group" = pairs per launch (>= 1, default 16 up to 4 Mpx frames, 8 above); "group_fine" = pairs per launch for the finest layer's sweeps
  * (default 1: one pair's working set stays in the Infinity Cache; 0 = same as group); "recompute" = 1: sweeps rebuild M
  * from (R0, R1, flow) on the fly instead of storing it (default 0); "pipeline" = 1: a second work set and stream prepare
  * group i + 1 (pyramid, expansions) while group i's finest-layer sweeps run (default 0: measured slower); "bands" = J in [1, 8]: the

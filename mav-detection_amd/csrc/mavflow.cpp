@@ -386,7 +386,10 @@ extern "C" int mav_create(mav_ctx** out, int device, int W, int H, int max_batch
     c->n1 = levels >= 1 ? (size_t)c->layers[1].w * c->layers[1].h : 0;
     c->htmp_stride = (size_t)H * W;                    // any layer (even layer 0 when its fast form does not apply) fits
     // group: pairs per launch for everything but the finest layer's sweeps (see farneback_group).
-    int group = max_batch < 8 ? max_batch : 8;
+    // (1080p, 64 pairs: 27.0 - 27.5 ms with groups of 16 or 32, 27.8 - 28.1 with 8, 28.4 with 4 -- the batched blur / expansion
+    // launches of 16 pairs run 10 - 15 % faster than two of 8; at 3840x2160 8 and 16 are equal, 4 is slower: profiles/r02/ab_group*.log)
+    int group = (size_t)W * H <= ((size_t)4 << 20) ? 16 : 8;
+    if (group > max_batch) group = max_batch;
     if (const char* e = getenv("MAVFLOW_GROUP")) { int v = atoi(e); if (v >= 1) group = v < max_batch ? v : max_batch; }
     if (const char* e = getenv("MAVFLOW_RC")) c->use_rc = atoi(e) != 0;
     if (const char* e = getenv("MAVFLOW_GROUP_FINE")) { int v = atoi(e); if (v >= 0) c->group_fine = v; }
