@@ -38,6 +38,12 @@ for case in range(n_cases):
     t0 = time.time()
     with _lib.Context(W, H, B, fb) as c:
         out = c.process_batch(prev, nxt, smp, want_phi=True)
+        # the same frames as ONE run (a frame sequence: every frame expanded once) must give the two-batch flow bit for bit
+        run = np.concatenate([prev, nxt[-1:]])
+        if B > 1:
+            c.set_option("group", int(rng.integers(1, B + 1)))
+        two = c.farneback(run[:-1].copy(), run[1:].copy())
+        assert np.array_equal(c.farneback_sequence(run), two), (case, W, H, "sequence")
     for b in range(B):
         ref = orc.calc(prev[b], nxt[b], po)
         e = np.hypot(out["flow"][b, ..., 0] - ref[..., 0], out["flow"][b, ..., 1] - ref[..., 1])
