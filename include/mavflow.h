@@ -79,7 +79,9 @@ int mav_device_count(void);       /* <= 0 when no GPU is visible */
  * group i + 1 (pyramid, expansions) while group i's finest-layer sweeps run (default 0: measured slower); "bands" = J in [1, 8]: the
  * finest layer's sweeps of a pair run band by band over J skewed horizontal bands (default: 1 up to ~2.6 Mpx, above that as many
  * bands as keep one band's working set inside the Infinity Cache); "share_frames" = 0: treat a frame sequence (see mav_farneback)
- * as independent pairs (default 1). MAV_ERR_ARG for unknown names. */
+ * as independent pairs (default 1); "pairs_in_flight" = 1 | 2 (default 2): the finest layer's per-pair work of a group alternates
+ * between two streams, each pair swept band by band (bands of <= 86 MB of working set, or "bands" when set) so that both stay in the
+ * Infinity Cache. MAV_ERR_ARG for unknown names. */
 int mav_set_option(mav_ctx*, const char* name, long value);
 int mav_num_layers(const mav_ctx*);
 int mav_layer_dims(const mav_ctx*, int k, int* w, int* h, int* ksize, double* sigma);
@@ -203,6 +205,10 @@ int mav_timer_stop(mav_ctx*, float* ms);
  * mav_profile_get: name[i] / total_ms[i] / launches[i] for i < *n (caller passes capacity in *n). */
 int mav_profile_enable(mav_ctx*, int on);
 int mav_profile_get(mav_ctx*, int* n, const char** names, double* total_ms, long* launches);
+/* Milliseconds during which at least one launch of the named kernel classes (comma-separated, names as mav_profile_get reports
+ * them) was running in the profiled calls: the union of the launches' intervals.  With two pairs in flight (option
+ * "pairs_in_flight") launches of one class overlap and their summed durations exceed the wall time. */
+int mav_profile_busy(mav_ctx*, const char* names, double* busy_ms);
 
 /* multi-GPU: gather `bytes_per_rank` bytes from every rank (RCCL ncclAllGather over xGMI) on the context's stream.
  * comm is an ncclComm_t created by the caller (mav_comm_* helpers below wrap RCCL's own bootstrap). */

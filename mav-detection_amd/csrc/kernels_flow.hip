@@ -523,11 +523,11 @@ template <int MODE>  // 0 zero, 1 upsample, 2 explicit
 __global__ __launch_bounds__(256) void k_update_matrices(const float* __restrict__ R0, const float* __restrict__ R1,
                                                          size_t R_stride, const float* __restrict__ fsrc, size_t f_stride,
                                                          int pw, int ph, float mul, double scale_x, double scale_y, int w,
-                                                         int h, float* __restrict__ M, size_t M_stride)
+                                                         int h, float* __restrict__ M, size_t M_stride, int y_begin, int y_end)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
+    const int y = y_begin + blockIdx.y * 4 + (threadIdx.x >> 6);          // rows [y_begin, y_end) of the layer only
+    if (x >= w || y >= y_end) return;
     const int s = blockIdx.z;
     float dx = 0.f, dy = 0.f;
     if (MODE == 1) {
@@ -542,15 +542,18 @@ __global__ __launch_bounds__(256) void k_update_matrices(const float* __restrict
 }
 
 void launch_update_matrices(hipStream_t st, const float* R0, const float* R1, size_t R_stride, const float* flow_prev,
-                            size_t fp_stride, int pw, int ph, float mul, int G, int w, int h, float* M, size_t M_stride)
+                            size_t fp_stride, int pw, int ph, float mul, int G, int w, int h, float* M, size_t M_stride, int y_begin, int y_end)
 {
-    dim3 grid((w + 63) / 64, (h + 3) / 4, G);
+    if (y_begin < 0) y_begin = 0;
+    if (y_end < 0 || y_end > h) y_end = h;
+    if (y_end <= y_begin) return;
+    dim3 grid((w + 63) / 64, (y_end - y_begin + 3) / 4, G);
     if (flow_prev)
         hipLaunchKernelGGL(k_update_matrices<1>, grid, dim3(256), 0, st, R0, R1, R_stride, flow_prev, fp_stride, pw, ph, mul,
-                           (double)pw / w, (double)ph / h, w, h, M, M_stride);
+                           (double)pw / w, (double)ph / h, w, h, M, M_stride, y_begin, y_end);
     else
         hipLaunchKernelGGL(k_update_matrices<0>, grid, dim3(256), 0, st, R0, R1, R_stride, (const float*)nullptr, (size_t)0,
-                           0, 0, 0.f, 0.0, 0.0, w, h, M, M_stride);
+                           0, 0, 0.f, 0.0, 0.0, w, h, M, M_stride, y_begin, y_end);
 }
 
 void launch_update_matrices_flow(hipStream_t st, const float* R0, const float* R1, size_t R_stride, const float* flow,
@@ -558,7 +561,7 @@ void launch_update_matrices_flow(hipStream_t st, const float* R0, const float* R
 {
     dim3 grid((w + 63) / 64, (h + 3) / 4, G);
     hipLaunchKernelGGL(k_update_matrices<2>, grid, dim3(256), 0, st, R0, R1, R_stride, flow, f_stride, 0, 0, 0.f, 0.0, 0.0,
-                       w, h, M, M_stride);
+                       w, h, M, M_stride, 0, h);
 }
 
 // ------------------------------------------------------------------------------------------------------------

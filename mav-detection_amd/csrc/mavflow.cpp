@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "mavflow_internal.h"
@@ -180,6 +181,7 @@ enum KernelId { K_BLUR_RESIZE, K_POLYEXP, K_UPDATE, K_ITER, K_ITER_COARSE, K_FOE
 static const char* const kKernelNames[K_COUNT] = {"blur_resize", "polyexp", "update_matrices", "blur_iter", "blur_iter_coarse",
                                                   "foe_ransac", "phi_mask_box", "misc"};
 struct ProfRec { int kid; hipEvent_t a, b; };
+struct ProfInterval { int kid; float t0, t1; };      // ms since the profile was switched on
 
 struct mav_ctx {
     int device = 0, W = 0, H = 0, max_batch = 0, group = 0, group_fine = 1;
@@ -209,6 +211,12 @@ struct mav_ctx {
     int nsets = 1;
     bool pipeline = false;           // option "pipeline" (off: measured 2 % slower): prepare group i + 1 while group i sweeps
     int bands = 1;                   // option "bands": the finest layer's sweeps in band-major order over this many skewed bands
+    // option "pairs_in_flight" (1 or 2): the finest layer's per-pair work (initial M + sweeps) of a group alternates between the
+    // compute stream and pair_stream, every pair band-major over bands of at most pif_band_mb of working set (layer_sweeps)
+    int pairs_in_flight = 2, pif_band_mb = 86;
+    bool bands_set = false;          // "bands" given explicitly (option or MAVFLOW_BANDS): that many bands in either schedule
+    hipStream_t pair_stream = nullptr;
+    hipEvent_t pif_fork = nullptr, pif_join = nullptr;
     bool share_frames = true;        // option "share_frames": expand a frame once when next == prev + one frame (a frame sequence)
     int coarse_cache_mb = 220;       // coarse layers: pairs per launch capped so that the sweeps' working set stays below this (0 = no cap)
     hipStream_t prep_stream = nullptr;
@@ -234,6 +242,8 @@ struct mav_ctx {
     hipEvent_t t0 = nullptr, t1 = nullptr;
     bool profiling = false;
     std::vector<ProfRec> prof;
+    std::vector<ProfInterval> prof_iv;          // every profiled launch as an interval (mav_profile_busy: union over concurrent streams)
+    hipEvent_t prof_base = nullptr;
     double prof_ms[K_COUNT] = {0};
     long prof_n[K_COUNT] = {0};
 };
@@ -295,6 +305,7 @@ extern "C" int mav_destroy(mav_ctx* c)
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto& l : c->layers) free_layer(l);
     if (c->prep_stream) hipStreamSynchronize(c->prep_stream);
+    if (c->pair_stream) hipStreamSynchronize(c->pair_stream);
     for (auto& w : c->ws) {
         void* wb[] = {w.I, w.R0, w.Ma, w.Mb, w.fc[0], w.fc[1], w.Htmp};      // R1 is the second half of R0's allocation
         for (void* b : wb) if (b) hipFree(b);
@@ -304,11 +315,13 @@ extern "C" int mav_destroy(mav_ctx* c)
     for (void* b : bufs) if (b) hipFree(b);
     for (auto& blk : c->scratch) if (blk.p) hipFree(blk.p);
     for (auto& r : c->prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    if (c->prof_base) hipEventDestroy(c->prof_base);
     if (c->t0) hipEventDestroy(c->t0);
     if (c->t1) hipEventDestroy(c->t1);
     if (c->copy_done) hipEventDestroy(c->copy_done);
     if (c->compute_mark) hipEventDestroy(c->compute_mark);
-    for (hipEvent_t e : {c->prep_done[0], c->prep_done[1], c->fine_done[0], c->fine_done[1], c->call_begin}) if (e) hipEventDestroy(e);
+    for (hipEvent_t e : {c->prep_done[0], c->prep_done[1], c->fine_done[0], c->fine_done[1], c->call_begin, c->pif_fork, c->pif_join}) if (e) hipEventDestroy(e);
+    if (c->pair_stream) hipStreamDestroy(c->pair_stream);
     if (c->prep_stream) hipStreamDestroy(c->prep_stream);
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -351,8 +364,9 @@ extern "C" int mav_create(mav_ctx** out, int device, int W, int H, int max_batch
     HIPB(hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming));
     HIPB(hipEventCreateWithFlags(&c->compute_mark, hipEventDisableTiming));
     HIPB(hipStreamCreateWithFlags(&c->prep_stream, hipStreamNonBlocking));
-    for (hipEvent_t* e : {&c->prep_done[0], &c->prep_done[1], &c->fine_done[0], &c->fine_done[1], &c->call_begin})
+    for (hipEvent_t* e : {&c->prep_done[0], &c->prep_done[1], &c->fine_done[0], &c->fine_done[1], &c->call_begin, &c->pif_fork, &c->pif_join})
         HIPB(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    HIPB(hipStreamCreateWithFlags(&c->pair_stream, hipStreamNonBlocking));
     HIPB(hipEventCreate(&c->t0));
     HIPB(hipEventCreate(&c->t1));
     if (!prepare_poly(fb.poly_n, fb.poly_sigma, &c->pc)) { fail(MAV_ERR_ARG, "poly_sigma %g gives a singular moment matrix", fb.poly_sigma); return bail(MAV_ERR_ARG); }
@@ -394,7 +408,9 @@ extern "C" int mav_create(mav_ctx** out, int device, int W, int H, int max_batch
     if (const char* e = getenv("MAVFLOW_RC")) c->use_rc = atoi(e) != 0;
     if (const char* e = getenv("MAVFLOW_GROUP_FINE")) { int v = atoi(e); if (v >= 0) c->group_fine = v; }
     if (const char* e = getenv("MAVFLOW_PIPELINE")) c->pipeline = atoi(e) != 0;
-    if (const char* e = getenv("MAVFLOW_BANDS")) { int v = atoi(e); if (v >= 1 && v <= 8) c->bands = v; }
+    if (const char* e = getenv("MAVFLOW_BANDS")) { int v = atoi(e); if (v >= 1 && v <= 8) { c->bands = v; c->bands_set = true; } }
+    if (const char* e = getenv("MAVFLOW_PAIRS_IN_FLIGHT")) { int v = atoi(e); if (v == 1 || v == 2) c->pairs_in_flight = v; }
+    if (const char* e = getenv("MAVFLOW_PIF_BAND_MB")) { int v = atoi(e); if (v >= 8) c->pif_band_mb = v; }
     if (const char* e = getenv("MAVFLOW_COARSE_MB")) { int v = atoi(e); if (v >= 0) c->coarse_cache_mb = v; }
     // One pair's finest-layer working set (80 B/px) fits the 256 MB Infinity Cache up to ~2.6 Mpx.  Beyond that the pair is swept
     // band by band (sweeps_band_major), bands of at most ~230 MB (measured at 3840x2160, 16 pairs: 3 bands 31.6 ms, 4 bands 32.4,
@@ -430,11 +446,18 @@ extern "C" int mav_set_option(mav_ctx* c, const char* name, long value)
         HIPCHK(hipSetDevice(c->device));
         HIPCHK(hipStreamSynchronize(c->stream));
         HIPCHK(hipStreamSynchronize(c->prep_stream));
+        HIPCHK(hipStreamSynchronize(c->pair_stream));
         return g == c->group ? MAV_OK : alloc_group(c, g);
     }
     if (!strcmp(name, "bands")) {
         if (value < 1 || value > 8) return fail(MAV_ERR_ARG, "bands must be in [1, 8]");
         c->bands = (int)value;
+        c->bands_set = true;
+        return MAV_OK;
+    }
+    if (!strcmp(name, "pairs_in_flight")) {
+        if (value != 1 && value != 2) return fail(MAV_ERR_ARG, "pairs_in_flight must be 1 or 2");
+        c->pairs_in_flight = (int)value;
         return MAV_OK;
     }
     if (!strcmp(name, "pipeline")) {      // the second work set exists only while the option is on
@@ -554,8 +577,11 @@ static int prof_collect(mav_ctx* c)
     if (c->prof.empty()) return MAV_OK;
     HIPCHK(hipStreamSynchronize(c->stream));
     for (auto& r : c->prof) {
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { c->prof_ms[r.kid] += ms; c->prof_n[r.kid]++; }
+        float ms = 0, t0 = 0;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            c->prof_ms[r.kid] += ms; c->prof_n[r.kid]++;
+            if (c->prof_base && hipEventElapsedTime(&t0, c->prof_base, r.a) == hipSuccess) c->prof_iv.push_back({r.kid, t0, t0 + ms});
+        }
         hipEventDestroy(r.a); hipEventDestroy(r.b);
     }
     c->prof.clear();
@@ -565,8 +591,42 @@ extern "C" int mav_profile_enable(mav_ctx* c, int on)
 {
     if (!c) return fail(MAV_ERR_ARG, "mav_profile_enable: NULL context");
     CHK(prof_collect(c));
-    if (on) { memset(c->prof_ms, 0, sizeof(c->prof_ms)); memset(c->prof_n, 0, sizeof(c->prof_n)); }
+    if (on) {
+        memset(c->prof_ms, 0, sizeof(c->prof_ms)); memset(c->prof_n, 0, sizeof(c->prof_n));
+        c->prof_iv.clear();
+        if (!c->prof_base) HIPCHK(hipEventCreate(&c->prof_base));
+        HIPCHK(hipEventRecord(c->prof_base, c->stream));
+    }
     c->profiling = on != 0;
+    return MAV_OK;
+}
+// Time during which at least one launch of the named kernel classes (comma-separated names of mav_profile_get) was running:
+// the union of the profiled launches' intervals.  With two pairs in flight launches of one class overlap, their summed
+// durations exceed the wall time and this is the figure a rate has to be quoted on.
+extern "C" int mav_profile_busy(mav_ctx* c, const char* names, double* busy_ms)
+{
+    if (!c || !names || !busy_ms) return fail(MAV_ERR_ARG, "mav_profile_busy: NULL argument");
+    CHK(prof_collect(c));
+    bool want[K_COUNT] = {false};
+    for (int i = 0; i < K_COUNT; i++) {
+        const char* p = strstr(names, kKernelNames[i]);
+        const size_t len = strlen(kKernelNames[i]);
+        while (p) {                                          // whole-name match between commas
+            if ((p == names || p[-1] == ',') && (p[len] == 0 || p[len] == ',')) { want[i] = true; break; }
+            p = strstr(p + 1, kKernelNames[i]);
+        }
+    }
+    std::vector<std::pair<float, float>> iv;
+    for (const auto& r : c->prof_iv) if (want[r.kid]) iv.push_back({r.t0, r.t1});
+    std::sort(iv.begin(), iv.end());
+    double busy = 0;
+    float lo = 0, hi = -1;
+    for (const auto& x : iv) {
+        if (hi < lo || x.first > hi) { if (hi >= lo) busy += hi - lo; lo = x.first; hi = x.second; }
+        else if (x.second > hi) hi = x.second;
+    }
+    if (hi >= lo) busy += hi - lo;
+    *busy_ms = busy;
     return MAV_OK;
 }
 extern "C" int mav_profile_get(mav_ctx* c, int* n, const char** names, double* total_ms, long* launches)
@@ -611,13 +671,23 @@ static BlurParams blur_of(const mav_ctx* c, const Layer& l)
 // (A two-stream variant of the same skew -- consecutive sweeps of one 1080p pair in flight together on different bands, to break
 // the lockstep of a per-pair launch -- was built, parity-green, and dropped: every cross-stream event wait costs ~6 us, 36.6 vs
 // 28.8 ms per 64 pairs.)
+// upd != nullptr: the initial M (UpdateMatrices from the coarser layer's flow) is built band by band too, right before a band's
+// first sweep: pixel rows [16 a0 - 8, 16 a1 + 8) -- what that sweep reads (6-pixel halo) -- which lie below everything the bands
+// above have written into Ma (their odd sweeps end one whole tile row higher); the rows two neighbouring bands both need are
+// simply built twice, to the same values.
+struct BandUpdate { const float* flow_prev; size_t fc_stride; int pw, ph; float mul; };
 static void sweeps_band_major(mav_ctx* c, hipStream_t st, int kid, float* Ma, float* Mb, const float* r0, const float* r1, int gs, int lw,
-                              int lh, int T, int J, float* fo, size_t fstride)
+                              int lh, int T, int J, float* fo, size_t fstride, const BandUpdate* upd = nullptr)
 {
     const size_t n0 = c->n0;
     const int I = c->fb.iterations;
     for (int j = 0; j < J; j++) {
         const int a0 = (int)((long long)T * j / J), a1 = (int)((long long)T * (j + 1) / J);
+        if (upd) {
+            ProfScope ps(c, K_UPDATE, st);
+            launch_update_matrices(st, r0, r1, 5 * n0, upd->flow_prev, upd->fc_stride, upd->pw, upd->ph, upd->mul, gs, lw, lh, Ma, 5 * n0,
+                                   j == 0 ? 0 : a0 * 16 - 8, j == J - 1 ? lh : a1 * 16 + 8);
+        }
         for (int it = 0; it < I; it++) {
             const int upd = it < I - 1;
             int ty0 = j == 0 ? 0 : a0 - it, ty1 = j == J - 1 ? T : a1 - it;
@@ -688,6 +758,49 @@ static void layer_sweeps(mav_ctx* c, mav_ctx::WorkSet& w, hipStream_t st, int k,
     // blur / expansion launches, 3.0 + 1.7 vs 2.0 + 0.9 ms, than the warmer initial M and first sweep return: 28.4 vs 27.4 ms.)
     static int share_m = -1;
     if (share_m < 0) { const char* e = getenv("MAVFLOW_SHARE_M"); share_m = e ? atoi(e) : 1; }
+    // TWO PAIRS IN FLIGHT (default; finest layer, one pair per launch).  Pair s0 of the group runs on stream s0 & 1 -- the compute
+    // stream and pair_stream -- and ping-pongs M through slot s0 & 1.  The two streams never wait for each other inside the group
+    // (different pairs: no dependency; one fork and one join event per group), so one stream's launches fill the kernel
+    // boundaries and the fill / drain of the other's.  What keeps this inside the 256 MB Infinity Cache is the band-major order:
+    // each pair is swept (and its initial M built) band by band, bands of at most 86 MB of working set -- 2 bands at 1080p, 8 at
+    // 3840x2160 -- so the hot set is 2 x 83 MB, what ONE whole 1080p pair occupies in the one-stream schedule.  Measured
+    // (profiles/r02/ab_two_pairs*.log): 1080p 25.9 - 26.3 vs 27.1 - 27.4 ms per 64 pairs, 4K 28.7 vs 30.1 ms per 16 pairs; two full
+    // pairs without bands 28.6 ms, three or four streams 27.9 - 28.1 ms.  Same tiles, same arithmetic as every other schedule:
+    // bit-identical flow (tests/test_gpu_flow.py).
+    if (k == 0 && c->pairs_in_flight == 2 && m_per_sub && sub == 1 && g >= 2 && st == c->stream && !c->pipeline) {
+        const int T = blur_iter_tile_rows(l.h);
+        const size_t ws = (size_t)l.w * l.h * 80, band = (size_t)c->pif_band_mb << 20;
+        int J = c->bands_set ? c->bands : (int)((ws + band - 1) / band);
+        const int Jmax = T / (c->fb.iterations + 2);          // a band needs iterations + 2 tile rows (the skew must not reach the image top)
+        if (J > Jmax) J = Jmax;
+        if (J < 1) J = 1;
+        if (J == 1 || blur_iter_bands_ok(l.w, c->fb.winsize, 5 * n0, 5 * n0, fstride, w.Ma, w.Mb, w.r0, w.r1, fdst)) {
+            hipEventRecord(c->pif_fork, st);
+            hipStreamWaitEvent(c->pair_stream, c->pif_fork, 0);
+            for (int s0 = 0; s0 < g; s0++) {
+                const hipStream_t ss = (s0 & 1) ? c->pair_stream : st;
+                float *Min = w.Ma + (size_t)(s0 & 1) * 5 * n0, *Mout = w.Mb + (size_t)(s0 & 1) * 5 * n0;
+                const float *r0 = w.r0 + (size_t)s0 * 5 * n0, *r1 = w.r1 + (size_t)s0 * 5 * n0;
+                float* fo = fdst + (size_t)s0 * fstride;
+                const BandUpdate bu{flow_prev ? flow_prev + (size_t)s0 * fc_stride : nullptr, fc_stride, pw, ph, mul};
+                if (J > 1) {
+                    sweeps_band_major(c, ss, K_ITER, Min, Mout, r0, r1, 1, l.w, l.h, T, J, fo, fstride, &bu);
+                    continue;
+                }
+                { ProfScope ps(c, K_UPDATE, ss);
+                  launch_update_matrices(ss, r0, r1, 5 * n0, bu.flow_prev, fc_stride, pw, ph, mul, 1, l.w, l.h, Min, 5 * n0); }
+                for (int it = 0; it < c->fb.iterations; it++) {
+                    const int upd = it < c->fb.iterations - 1;
+                    { ProfScope ps(c, K_ITER, ss);
+                      launch_blur_iter(ss, Min, Mout, 5 * n0, r0, r1, 5 * n0, 1, l.w, l.h, c->fb.winsize, upd, !upd, fo, fstride); }
+                    if (upd) { float* t = Min; Min = Mout; Mout = t; }
+                }
+            }
+            hipEventRecord(c->pif_join, c->pair_stream);
+            hipStreamWaitEvent(st, c->pif_join, 0);
+            return;
+        }
+    }
     for (int s0 = 0; s0 < g; s0 += sub) {
         const int gs = g - s0 < sub ? g - s0 : sub;
         const size_t m_off = (m_per_sub && share_m) ? 0 : (size_t)s0 * 5 * n0;

@@ -45,7 +45,8 @@ void launch_polyexp(hipStream_t st, const float* I, size_t I_stride, int G, int 
                     size_t R_stride);
 // flow_prev == nullptr: zero initial flow. Otherwise flow = resize(prev (ph x pw x 2))*mul, evaluated inline.
 void launch_update_matrices(hipStream_t st, const float* R0, const float* R1, size_t R_stride, const float* flow_prev,
-                            size_t fp_stride, int pw, int ph, float mul, int G, int w, int h, float* M, size_t M_stride);
+                            size_t fp_stride, int pw, int ph, float mul, int G, int w, int h, float* M, size_t M_stride,
+                            int y_begin = 0, int y_end = -1 /* pixel rows [y_begin, y_end) only; -1 = to the bottom */);
 // explicit per-pixel flow (h x w x 2), used by the stage hook
 void launch_update_matrices_flow(hipStream_t st, const float* R0, const float* R1, size_t R_stride, const float* flow,
                                  size_t f_stride, int G, int w, int h, float* M, size_t M_stride);

@@ -44,7 +44,7 @@ EXPORTS = [
     "mav_device_count", "mav_set_option", "mav_num_layers", "mav_layer_dims", "mav_farneback", "mav_derotate",
     "mav_foe_dense", "mav_ransac", "mav_bgr2gray", "mav_phi_mask", "mav_bbox", "mav_window_max", "mav_tpr_fpr_counts", "mav_process_batch",
     "mav_farneback_dev", "mav_process_batch_dev", "mav_sync", "mav_stream", "mav_dev_alloc", "mav_dev_free",
-    "mav_memcpy_h2d", "mav_memcpy_d2h", "mav_host_alloc", "mav_host_free", "mav_upload_async", "mav_upload_fence", "mav_timer_start", "mav_timer_stop", "mav_profile_enable", "mav_profile_get",
+    "mav_memcpy_h2d", "mav_memcpy_d2h", "mav_host_alloc", "mav_host_free", "mav_upload_async", "mav_upload_fence", "mav_timer_start", "mav_timer_stop", "mav_profile_enable", "mav_profile_get", "mav_profile_busy",
     "mav_comm_unique_id", "mav_comm_init", "mav_comm_destroy", "mav_allgather_results", "mav_stage_blur_resize",
     "mav_stage_polyexp", "mav_stage_update_matrices", "mav_stage_blur_iter",
     "mav_analyze_pyramid", "mav_pyramid_levels", "mav_pyramid_dims", "mav_optimize_window", "mav_stage_pyramid_level",
@@ -119,6 +119,7 @@ def load() -> C.CDLL:
     lib.mav_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
     lib.mav_profile_enable.argtypes = [vp, C.c_int]
     lib.mav_profile_get.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_long)]
+    lib.mav_profile_busy.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double)]
     lib.mav_comm_unique_id.argtypes = [vp]
     lib.mav_comm_init.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
     lib.mav_comm_destroy.argtypes = [vp]
@@ -573,6 +574,12 @@ class Context:
         cnt = (C.c_long * 16)()
         check(self.lib.mav_profile_get(self.h, C.byref(n), names, ms, cnt))
         return {names[i].decode(): (ms[i], cnt[i]) for i in range(n.value)}
+
+    def profile_busy(self, *names: str) -> float:
+        """ms during which at least one launch of the named kernel classes was running (union of the launches' intervals)."""
+        out = C.c_double()
+        check(self.lib.mav_profile_busy(self.h, ",".join(names).encode(), C.byref(out)))
+        return out.value
 
     # -- stage hooks (parity tests) --------------------------------------------------------------------------
     def stage_phi_mask(self, flow32, foe, omega=None, dt=None, sky=None, params: ThrParams | None = None, want_phi=False):

@@ -270,13 +270,16 @@ def test_band_major_sweeps_are_bit_identical(mav, size):
     W, H = size
     prev, nxt = synth.make_batch(W, H, 3, distinct=3)
     with _lib.Context(W, H, 3) as c:
+        c.set_option("pairs_in_flight", 1)
         c.set_option("bands", 1)
         ref = c.farneback(prev, nxt)
         one = c.farneback(prev[:1], nxt[:1])
-        for bands in (2, 3):
-            c.set_option("bands", bands)
-            assert np.array_equal(c.farneback(prev, nxt), ref), bands
-            assert np.array_equal(c.farneback(prev[:1], nxt[:1]), one), bands
+        for pif in (1, 2):                               # one stream, and two pairs in flight on two streams
+            c.set_option("pairs_in_flight", pif)
+            for bands in (1, 2, 3):
+                c.set_option("bands", bands)
+                assert np.array_equal(c.farneback(prev, nxt), ref), (pif, bands)
+                assert np.array_equal(c.farneback(prev[:1], nxt[:1]), one), (pif, bands)
         c.set_option("group", 2)                       # a group of 2 + a group of 1
         assert np.array_equal(c.farneback(prev, nxt), ref)
 
@@ -346,3 +349,37 @@ def test_frame_sequence_shares_expansions_bit_identical(mav):
         c.set_option("share_frames", 1)
         c.set_option("group", 5)                                                            # one group of five pairs = six frames
         assert np.array_equal(c.farneback_sequence(frames), ref)
+
+
+@pytest.mark.parametrize("size,batch,group", [((640, 480), 5, 4), ((640, 480), 7, 3), ((1000, 562), 4, 4), ((1920, 1080), 5, 5)])
+def test_two_pairs_in_flight_give_the_same_flow(mav, size, batch, group):
+    """The default schedule of the finest layer: pair s of a group on stream s & 1, M through slot s & 1, every pair band-major with
+    its initial M built band by band (option "pairs_in_flight" = 2).  Same tiles and arithmetic as the one-stream, sweep-major,
+    whole-frame-initial-M schedule: bit-identical flow, call after call, for odd and even group sizes and a ragged last group, and
+    through the fused chain."""
+    from mavflow import _lib
+    W, H = size
+    prev, nxt = synth.make_batch(W, H, batch, distinct=min(batch, 4))
+    smp = np.stack([synth.foe_samples(W, H, b) for b in range(batch)])
+    with _lib.Context(W, H, batch) as c:
+        c.set_option("group", group)
+        c.set_option("pairs_in_flight", 1)
+        ref = c.farneback(prev, nxt)
+        chain = c.process_batch(prev, nxt, smp)
+        c.set_option("pairs_in_flight", 2)
+        for rep in range(3):
+            out = c.farneback(prev, nxt)
+            assert np.array_equal(out, ref), (rep, int((out != ref).sum()))
+        assert np.array_equal(c.farneback(prev[:3], nxt[:3]), ref[:3])
+        assert np.array_equal(c.farneback(prev[:1], nxt[:1]), ref[:1])
+        two = c.process_batch(prev, nxt, smp)
+        for key in ("flow", "mask_fixed", "mask_dyn"):
+            assert np.array_equal(two[key], chain[key]), key
+        assert two["results"].tobytes() == chain["results"].tobytes()
+        # the profile's interval union: launches of one class overlap, the busy time stays below their sum
+        c.profile_enable(True)
+        c.farneback(prev, nxt)
+        prof = c.profile_get()
+        busy = c.profile_busy("blur_iter")
+        c.profile_enable(False)
+        assert 0 < busy <= prof["blur_iter"][0] * 1.0001

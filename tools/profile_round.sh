@@ -11,4 +11,9 @@ tools/pmc_passes.sh "$out/pmc1080" --batch 64 > "$out/pmc1080.log" 2>&1 || exit 
 tools/pmc_passes.sh "$out/pmc4k" $B4K > "$out/pmc4k.log" 2>&1 || exit 1
 python3 tools/make_traffic.py "$out/pmc1080" "$out/traffic.json" --batch 64 > /dev/null || exit 1
 python3 tools/make_traffic.py "$out/pmc4k" "$out/traffic_4k.json" --width 3840 --height 2160 --levels 5 --batch 16 > /dev/null || exit 1
+# sweep launches overlap (two pairs in flight): busy time = union of the dispatch intervals of the kernel trace
+for t in kt1080 kt4k; do
+  per=$(python3 -c "import json,sys; print(json.loads(open('$out/$t.json').readline())['roofline']['alg_bytes_per_launch_avg'])")
+  python3 tools/trace_union.py "$out"/$t/runc/*_kernel_trace.csv --bytes-per-dispatch "$per" > "$out/sweep_busy_$t.txt" || exit 1
+done
 find "$out" -name "*kernel_stats.csv" | head
