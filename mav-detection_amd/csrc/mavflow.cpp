@@ -801,6 +801,39 @@ static void layer_sweeps(mav_ctx* c, mav_ctx::WorkSet& w, hipStream_t st, int k,
             return;
         }
     }
+    // COARSE LAYERS with two sub-groups in flight (option "pairs_in_flight" = 2): sub-groups of half the cache-sized count alternate
+    // between the compute stream and pair_stream, each with its own M slots, for the same reason as the pairs of the finest layer
+    // below -- 25.5 - 25.6 vs 26.0 - 26.6 ms per 64 pairs at 1080p with 4 + 4 instead of 8 pairs per launch (3 + 3: 25.7 - 25.8;
+    // 8 + 8: 26.4; profiles/r02/ab_coarse_two*.log).
+    if (k > 0 && c->pairs_in_flight == 2 && g >= 2 && st == c->stream && !c->pipeline && !rc_ok) {
+        int half = sub / 2 > 0 ? sub / 2 : 1;
+        static int coarse_half = -1;
+        if (coarse_half < 0) { const char* e = getenv("MAVFLOW_COARSE_HALF"); coarse_half = e ? atoi(e) : 0; }
+        if (coarse_half > 0) half = coarse_half;
+        if (2 * half > g) half = (g + 1) / 2;
+        hipEventRecord(c->pif_fork, st);
+        hipStreamWaitEvent(c->pair_stream, c->pif_fork, 0);
+        int idx = 0;
+        for (int s0 = 0; s0 < g; s0 += half, idx++) {
+            const int gs = g - s0 < half ? g - s0 : half;
+            const hipStream_t ss = (idx & 1) ? c->pair_stream : st;
+            const size_t m_off = (size_t)(idx & 1) * half * 5 * n0;
+            float *Min = w.Ma + m_off, *Mout = w.Mb + m_off;
+            const float *r0 = w.r0 + (size_t)s0 * 5 * n0, *r1 = w.r1 + (size_t)s0 * 5 * n0;
+            { ProfScope ps(c, K_UPDATE, ss);
+              launch_update_matrices(ss, r0, r1, 5 * n0, flow_prev ? flow_prev + (size_t)s0 * fc_stride : nullptr, fc_stride, pw, ph, mul, gs, l.w, l.h,
+                                     Min, 5 * n0); }
+            for (int it = 0; it < c->fb.iterations; it++) {
+                const int upd = it < c->fb.iterations - 1;
+                { ProfScope ps(c, K_ITER_COARSE, ss);
+                  launch_blur_iter(ss, Min, Mout, 5 * n0, r0, r1, 5 * n0, gs, l.w, l.h, c->fb.winsize, upd, !upd, fdst + (size_t)s0 * fstride, fstride); }
+                if (upd) { float* t = Min; Min = Mout; Mout = t; }
+            }
+        }
+        hipEventRecord(c->pif_join, c->pair_stream);
+        hipStreamWaitEvent(st, c->pif_join, 0);
+        return;
+    }
     for (int s0 = 0; s0 < g; s0 += sub) {
         const int gs = g - s0 < sub ? g - s0 : sub;
         const size_t m_off = (m_per_sub && share_m) ? 0 : (size_t)s0 * 5 * n0;
