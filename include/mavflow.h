@@ -201,7 +201,9 @@ int mav_upload_fence(mav_ctx*);
 /* HIP-event timing on the context's stream (bench.py): start/stop bracket enqueued work; stop synchronises. */
 int mav_timer_start(mav_ctx*);
 int mav_timer_stop(mav_ctx*, float* ms);
-/* Per-kernel-class profiling with HIP events around every launch (separate pass, never inside a timed region).
+/* Per-kernel-class profiling with HIP events (separate pass, never inside a timed region).  on = 1: events around every launch
+ * (durations and launch counts per class); on = 2: events around every RUN of consecutive launches of one class on a stream -- a tenth
+ * of the events, for mav_profile_busy, which then sees the two streams overlap almost undisturbed (total_ms / launches then count runs).
  * mav_profile_get: name[i] / total_ms[i] / launches[i] for i < *n (caller passes capacity in *n). */
 int mav_profile_enable(mav_ctx*, int on);
 int mav_profile_get(mav_ctx*, int* n, const char** names, double* total_ms, long* launches);

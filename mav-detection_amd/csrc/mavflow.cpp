@@ -240,7 +240,9 @@ struct mav_ctx {
     size_t pyr_ws_bytes = 0;
     unsigned long long* sat = nullptr;          // optimize_window summed-area tables (lazily, max_batch)
     hipEvent_t t0 = nullptr, t1 = nullptr;
-    bool profiling = false;
+    int profiling = 0;               // 0 off; 1 = HIP events around every launch; 2 = around every RUN of launches of one class on a stream
+    struct OpenRun { hipStream_t st; int kid; hipEvent_t a; };
+    std::vector<OpenRun> open_runs;  // mode 2: the run in progress on each stream
     std::vector<ProfRec> prof;
     std::vector<ProfInterval> prof_iv;          // every profiled launch as an interval (mav_profile_busy: union over concurrent streams)
     hipEvent_t prof_base = nullptr;
@@ -248,15 +250,42 @@ struct mav_ctx {
     long prof_n[K_COUNT] = {0};
 };
 
+// mode 2: the end event of a run is recorded when the next launch on that stream belongs to another class (or at collection): it
+// completes, in stream order, when the run's last kernel has -- two events per run instead of two per launch, so that the
+// overlap of the two streams is measured almost undisturbed (mav_profile_busy)
+static void close_run(mav_ctx* c, size_t i)
+{
+    mav_ctx::OpenRun r = c->open_runs[i];
+    hipEvent_t b = nullptr;
+    hipEventCreate(&b);
+    hipEventRecord(b, r.st);
+    c->prof.push_back({r.kid, r.a, b});
+    c->open_runs.erase(c->open_runs.begin() + i);
+}
+static void prof_close_stream(mav_ctx* c, hipStream_t st)       // before a stream waits for another one: the wait is not part of the run
+{
+    for (size_t i = 0; i < c->open_runs.size(); i++) if (c->open_runs[i].st == st) { close_run(c, i); return; }
+}
 struct ProfScope {
     mav_ctx* c; int kid; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
     ProfScope(mav_ctx* c_, int k, hipStream_t st_ = nullptr) : c(c_), kid(k), st(st_ ? st_ : c_->stream)
     {
-        if (c->profiling) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, st); }
+        if (c->profiling == 1) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, st); }
+        else if (c->profiling == 2) {
+            for (size_t i = 0; i < c->open_runs.size(); i++)
+                if (c->open_runs[i].st == st) {
+                    if (c->open_runs[i].kid == kid) return;          // the run goes on
+                    close_run(c, i);
+                    break;
+                }
+            hipEventCreate(&a);
+            hipEventRecord(a, st);
+            c->open_runs.push_back({st, kid, a});
+        }
     }
     ~ProfScope()
     {
-        if (c->profiling) { hipEventRecord(b, st); c->prof.push_back({kid, a, b}); }
+        if (c->profiling == 1) { hipEventRecord(b, st); c->prof.push_back({kid, a, b}); }
     }
 };
 
@@ -574,8 +603,10 @@ extern "C" int mav_timer_stop(mav_ctx* c, float* ms)
 
 static int prof_collect(mav_ctx* c)
 {
+    while (!c->open_runs.empty()) close_run(c, c->open_runs.size() - 1);
     if (c->prof.empty()) return MAV_OK;
     HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipStreamSynchronize(c->pair_stream));
     for (auto& r : c->prof) {
         float ms = 0, t0 = 0;
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
@@ -597,7 +628,7 @@ extern "C" int mav_profile_enable(mav_ctx* c, int on)
         if (!c->prof_base) HIPCHK(hipEventCreate(&c->prof_base));
         HIPCHK(hipEventRecord(c->prof_base, c->stream));
     }
-    c->profiling = on != 0;
+    c->profiling = on == 2 ? 2 : (on != 0);
     return MAV_OK;
 }
 // Time during which at least one launch of the named kernel classes (comma-separated names of mav_profile_get) was running:
@@ -796,7 +827,8 @@ static void layer_sweeps(mav_ctx* c, mav_ctx::WorkSet& w, hipStream_t st, int k,
                     if (upd) { float* t = Min; Min = Mout; Mout = t; }
                 }
             }
-            hipEventRecord(c->pif_join, c->pair_stream);
+            prof_close_stream(c, c->pair_stream); prof_close_stream(c, st);
+        hipEventRecord(c->pif_join, c->pair_stream);
             hipStreamWaitEvent(st, c->pif_join, 0);
             return;
         }
@@ -830,6 +862,7 @@ static void layer_sweeps(mav_ctx* c, mav_ctx::WorkSet& w, hipStream_t st, int k,
                 if (upd) { float* t = Min; Min = Mout; Mout = t; }
             }
         }
+        prof_close_stream(c, c->pair_stream); prof_close_stream(c, st);
         hipEventRecord(c->pif_join, c->pair_stream);
         hipStreamWaitEvent(st, c->pif_join, 0);
         return;
