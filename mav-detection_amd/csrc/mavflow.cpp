@@ -777,7 +777,8 @@ static void layer_sweeps(mav_ctx* c, mav_ctx::WorkSet& w, hipStream_t st, int k,
     // still in the Infinity Cache when the first sweep reads them (measured -0.5 ms per 64 pairs; doing the same with the
     // blur and the expansion costs more in small launches than it returns)
     const bool m_per_sub = sub < g;
-    if (!m_per_sub) {
+    const bool coarse_two = k > 0 && c->pairs_in_flight == 2 && g >= 2 && st == c->stream && !c->pipeline;     // see below
+    if (!m_per_sub && !coarse_two) {
         ProfScope ps(c, K_UPDATE, st);
         launch_update_matrices(st, w.r0, w.r1, 5 * n0, flow_prev, fc_stride, pw, ph, mul, g, l.w, l.h, w.Ma, 5 * n0);
     }
@@ -828,16 +829,16 @@ static void layer_sweeps(mav_ctx* c, mav_ctx::WorkSet& w, hipStream_t st, int k,
                 }
             }
             prof_close_stream(c, c->pair_stream); prof_close_stream(c, st);
-        hipEventRecord(c->pif_join, c->pair_stream);
+            hipEventRecord(c->pif_join, c->pair_stream);
             hipStreamWaitEvent(st, c->pif_join, 0);
             return;
         }
     }
     // COARSE LAYERS with two sub-groups in flight (option "pairs_in_flight" = 2): sub-groups of half the cache-sized count alternate
     // between the compute stream and pair_stream, each with its own M slots, for the same reason as the pairs of the finest layer
-    // below -- 25.5 - 25.6 vs 26.0 - 26.6 ms per 64 pairs at 1080p with 4 + 4 instead of 8 pairs per launch (3 + 3: 25.7 - 25.8;
+    // above -- 25.5 - 25.6 vs 26.0 - 26.6 ms per 64 pairs at 1080p with 4 + 4 instead of 8 pairs per launch (3 + 3: 25.7 - 25.8;
     // 8 + 8: 26.4; profiles/r02/ab_coarse_two*.log).
-    if (k > 0 && c->pairs_in_flight == 2 && g >= 2 && st == c->stream && !c->pipeline && !rc_ok) {
+    if (coarse_two) {
         int half = sub / 2 > 0 ? sub / 2 : 1;
         static int coarse_half = -1;
         if (coarse_half < 0) { const char* e = getenv("MAVFLOW_COARSE_HALF"); coarse_half = e ? atoi(e) : 0; }
