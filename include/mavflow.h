@@ -73,16 +73,29 @@ int mav_create(mav_ctx** out, int device, int W, int H, int max_batch, const mav
 int mav_destroy(mav_ctx*);
 const char* mav_last_error(void); /* thread-local, never NULL */
 int mav_device_count(void);       /* <= 0 when no GPU is visible */
-/* Tuning: "group" = pairs per launch (>= 1, default 16 up to 4 Mpx frames, 8 above); "group_fine" = pairs per launch for the finest layer's sweeps
- * (default 1: one pair's working set stays in the Infinity Cache; 0 = same as group); "recompute" = 1: sweeps rebuild M
- * from (R0, R1, flow) on the fly instead of storing it (default 0); "pipeline" = 1: a second work set and stream prepare
- * group i + 1 (pyramid, expansions) while group i's finest-layer sweeps run (default 0: measured slower); "bands" = J in [1, 8]: the
- * finest layer's sweeps of a pair run band by band over J skewed horizontal bands (default: 1 up to ~2.6 Mpx, above that as many
- * bands as keep one band's working set inside the Infinity Cache); "share_frames" = 0: treat a frame sequence (see mav_farneback)
- * as independent pairs (default 1); "pairs_in_flight" = 1 | 2 (default 2): the finest layer's per-pair work of a group alternates
- * between two streams, each pair swept band by band (bands of <= 86 MB of working set, or "bands" when set) so that both stay in the
- * Infinity Cache. MAV_ERR_ARG for unknown names. */
+/* Scheduling / tuning options (every switch of the library is here: it reads no environment variable).  MAV_ERR_ARG for unknown
+ * names or values out of range.
+ *   "group"            pairs per launch for everything but the finest layer's sweeps (default 16 up to 4 Mpx frames, 8 above)
+ *   "group_fine"       pairs per launch for the finest layer's sweeps (default 1: one pair's working set stays in the Infinity Cache;
+ *                      0 = same as group)
+ *   "pairs_in_flight"  1 | 2 (default 2): the finest layer's per-pair work of a group alternates between two streams, every pair swept
+ *                      band by band (bands of <= "band_mb" MB of working set, default 86, or "bands" when set) so that both stay in
+ *                      the Infinity Cache; the coarse layers alternate sub-groups of "coarse_half" pairs (0 = half the count that fits
+ *                      "coarse_cache_mb", default 220) between the two streams
+ *   "bands"            J in [1, 8]: a pair's finest-layer sweeps run band by band over J skewed horizontal bands (default: 1 up to
+ *                      ~2.6 Mpx, above that as many as keep a band's working set inside the Infinity Cache)
+ *   "share_m"          one-stream schedule: all pairs of a group ping-pong M through the first slot's buffers (default 1)
+ *   "share_frames"     0: treat a frame sequence (see mav_farneback) as independent pairs (default 1)
+ *   "strip"            width in tiles of the column strips of the XCD-aware tile order (0 = automatic)
+ *   "phi_screen"       0: every pixel of the phi / threshold stage takes the exact path (default 1: float32 screen in front of it)
+ *   "phi_yloop"        16-row blocks per workgroup of the phi kernel (0 = automatic)
+ * None of them changes a result bit (tests/test_gpu_flow.py, tests/test_gpu_screen.py). */
 int mav_set_option(mav_ctx*, const char* name, long value);
+int mav_get_option(mav_ctx*, const char* name, long* value);
+/* The schedule a call of `batch` pairs takes with the options in effect, as one line of JSON: every option above, the group split,
+ * whether the small-batch schedule applies and, per layer, the blur form and how the sweeps run (pairs per launch, bands).
+ * bench.py prints it into its record and hashes it together with the kernel sources. */
+int mav_schedule_info(mav_ctx*, int batch, char* buf, size_t cap);
 int mav_num_layers(const mav_ctx*);
 int mav_layer_dims(const mav_ctx*, int k, int* w, int* h, int* ksize, double* sigma);
 
@@ -111,7 +124,7 @@ int mav_phi_mask(mav_ctx*, const double* flow, const double* foe, const uint8_t*
  * input, src/detector.py:80-81): numpy then evaluates the |flow2| gate (:78), get_phi (:163-177, zeros_like keeps float32) and
  * the threshold block in float32.  Same arithmetic here, in numpy's operation order; the line intersections stay in double
  * (float32 + uint32 promotes).  phi / max_phi are float32.  arccos: correctly rounded float32 (numpy's own float32 arccos is a
- * SIMD routine up to 2 ulp away from that, host dependent -- see tests/test_gpu_frame0.py). */
+ * SIMD routine up to 2 ulp away from that, host dependent -- see tests/test_frame0.py). */
 int mav_foe_dense_f32(mav_ctx*, const float* flow, const uint32_t* samples, int batch, const mav_foe_params*, double* foe);
 int mav_phi_mask_f32(mav_ctx*, const float* flow, const double* foe, const uint8_t* sky, int batch, const mav_thr_params*,
                      float* phi, uint8_t* mask_fixed, uint8_t* mask_dyn, float* max_phi);
@@ -222,6 +235,9 @@ int mav_allgather_results(mav_ctx*, void* comm, const void* local_dev, size_t by
 /* ---- stage hooks (diagnostics / parity tests; host pointers, one image or pair, SoA planes) ------------- */
 /* layer image I_k of one frame: convertTo(f32) -> GaussianBlur -> resize   (h_k, w_k) */
 int mav_stage_blur_resize(mav_ctx*, const uint8_t* img, int k, float* out);
+/* the same through the separable two-pass kernels (H x w scratch in memory) that layers with a long Gaussian use: layers with a
+ * short one go through ONE fused kernel in the product path, and the two forms must agree bit for bit */
+int mav_stage_blur_resize_two_pass(mav_ctx*, const uint8_t* img, int k, float* out);
 /* FarnebackPolyExp of a (h, w) f32 image at layer k -> R as 5 planes (5, h, w) */
 int mav_stage_polyexp(mav_ctx*, const float* I, int k, float* R);
 /* FarnebackUpdateMatrices at layer k: R0, R1 (5,h,w), flow (h,w,2) -> M (5,h,w) */

@@ -12,7 +12,6 @@
 
 #include <limits.h>
 #include <math.h>
-#include <stdlib.h>
 
 #include <type_traits>
 
@@ -79,7 +78,8 @@ void launch_derotate(hipStream_t st, const float* flow, const DerotParams* derot
 template <typename FlowT>
 __global__ __launch_bounds__(1024) void k_foe_candidates(const FlowT* __restrict__ flow, const DerotParams* __restrict__ derot,
                                                          const uint32_t* __restrict__ samples, int W, int H, int N,
-                                                         double mag2_thr, float mag2_thr_f32, FoeScratch sc)
+                                                         double mag2_thr, float mag2_thr_f32, FoeScratch sc,
+                                                         int32_t* __restrict__ box_acc, unsigned long long* __restrict__ max_phi_bits)
 {
     __shared__ int wave_tot[16];
     __shared__ int base_s;
@@ -92,7 +92,12 @@ __global__ __launch_bounds__(1024) void k_foe_candidates(const FlowT* __restrict
     const bool f32_gate = std::is_same<FlowT, float>::value && dp && dp->mode == MAV_PAIR_FRAME0;
     const uint32_t* smp = samples + (size_t)b * 4 * N;
     double* cand = sc.cand + (size_t)b * 2 * N;
-    if (tid == 0) { base_s = 0; sc.best_key[b] = 0ull; }
+    if (tid == 0) {
+        base_s = 0; sc.best_key[b] = 0ull;
+        sc.done[2 * b] = 0u; sc.done[2 * b + 1] = 0u;           // tickets of the vote and of the phi kernel (both run after this one)
+        if (box_acc) { box_acc[4 * b] = INT_MAX; box_acc[4 * b + 1] = INT_MAX; box_acc[4 * b + 2] = -1; box_acc[4 * b + 3] = -1; }
+        if (max_phi_bits) max_phi_bits[b] = 0ull;
+    }
     __syncthreads();
     for (int i0 = 0; i0 < N; i0 += 1024) {
         const int i = i0 + tid;
@@ -149,84 +154,103 @@ __global__ __launch_bounds__(1024) void k_foe_candidates(const FlowT* __restrict
 }
 
 // RANSAC vote: score_i = #{j : |e_j - e_i| < r} - 1; winner = largest score, lowest index (strict > in the loop).
-// Grid (ceil(N/256), B): each workgroup holds all candidates of its pair in LDS and scores 256 of them.
-__global__ __launch_bounds__(256) void k_ransac(FoeScratch sc, int N, double dist2_thr)
+// One WAVE scores four candidates against all M: its lanes stride over j (one coalesced double2 load feeds the four tests), the
+// counts are reduced over the wave.  Grid (ceil(N/16), B).  (Round 2's form -- one THREAD per candidate, 4 workgroups per pair --
+// took 23 us for a single pair: a thousand dependent LDS reads per thread.)  The workgroup whose ticket is last reads the winner
+// and writes the pair's FoE: no separate finalize launch.  Every workgroup's atomicMax has returned before its ticket is drawn.
+__global__ __launch_bounds__(256) void k_ransac(FoeScratch sc, int N, double dist2_thr, double* __restrict__ foe)
 {
-    extern __shared__ __attribute__((aligned(16))) double2 e[];
-    const int b = blockIdx.y, tid = threadIdx.x;
+    __shared__ unsigned long long wkey[4];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int M = sc.count[b];
-    if ((int)(blockIdx.x * 256) >= M) return;
     const double2* cand = (const double2*)(sc.cand + (size_t)b * 2 * N);
-    for (int j = tid; j < M; j += 256) e[j] = cand[j];
-    __syncthreads();
-    const int i = blockIdx.x * 256 + tid;
+    const int i0 = ((int)blockIdx.x * 4 + wv) * 4;
     unsigned long long key = 0ull;
-    if (i < M) {
-        const double2 ei = e[i];
-        int cnt = 0;
-        for (int j = 0; j < M; j++) {
-            const double dx = e[j].x - ei.x, dy = e[j].y - ei.y;
-            const double d2 = dx * dx + dy * dy;
-            cnt += (d2 < dist2_thr) ? 1 : 0;  // == (sqrt(d2) < ransac_threshold)
+    if (i0 < M) {
+        double2 e[4];
+        int cnt[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 4; k++) e[k] = cand[min(i0 + k, M - 1)];
+        for (int j = lane; j < M; j += 64) {
+            const double2 c = cand[j];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const double dx = c.x - e[k].x, dy = c.y - e[k].y;
+                const double d2 = dx * dx + dy * dy;
+                cnt[k] += (d2 < dist2_thr) ? 1 : 0;  // == (sqrt(d2) < ransac_threshold)
+            }
         }
-        const int score = cnt - 1;
-        if (score > 0) key = ((unsigned long long)(unsigned)score << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            for (int o = 32; o > 0; o >>= 1) cnt[k] += __shfl_xor(cnt[k], o);
+            const int score = cnt[k] - 1;
+            if (i0 + k < M && score > 0) {
+                const unsigned long long kk = ((unsigned long long)(unsigned)score << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)(i0 + k));
+                key = kk > key ? kk : key;
+            }
+        }
     }
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long other = __shfl_xor(key, o);
-        key = other > key ? other : key;
+    if (lane == 0) wkey[wv] = key;
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 1; k < 4; k++) key = wkey[k] > key ? wkey[k] : key;
+        unsigned long long seen = 0ull;
+        if (key) seen = atomicMax(&sc.best_key[b], key);              // returning form: performed before the ticket below
+        asm volatile("s_waitcnt vmcnt(0)" ::"v"(seen) : "memory");
+        const unsigned ticket = atomicAdd(&sc.done[2 * b], 1u);
+        if (ticket == gridDim.x - 1) {
+            const unsigned long long best = __hip_atomic_load(&sc.best_key[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            double x = 0.0, y = 0.0;
+            if (best) {
+                const unsigned idx = 0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFull);
+                x = sc.cand[(size_t)b * 2 * N + 2 * idx];
+                y = sc.cand[(size_t)b * 2 * N + 2 * idx + 1];
+            }
+            foe[2 * b] = x;
+            foe[2 * b + 1] = y;
+            __hip_atomic_store(&sc.done[2 * b], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
-    if ((tid & 63) == 0 && key) atomicMax(&sc.best_key[b], key);
-}
-
-__global__ void k_foe_finalize(FoeScratch sc, int N, int B, double* __restrict__ foe)
-{
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    const unsigned long long key = sc.best_key[b];
-    double x = 0.0, y = 0.0;
-    if (key) {
-        const unsigned idx = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
-        x = sc.cand[(size_t)b * 2 * N + 2 * idx];
-        y = sc.cand[(size_t)b * 2 * N + 2 * idx + 1];
-    }
-    foe[2 * b] = x;
-    foe[2 * b + 1] = y;
 }
 
 template <typename FlowT>
 static void launch_foe_t(hipStream_t st, const FlowT* flow, const DerotParams* derot, const uint32_t* samples, int B, int W,
-                         int H, int N, double mag2_thr, float mag2_thr_f32, double dist2_thr, FoeScratch s, double* foe)
+                         int H, int N, double mag2_thr, float mag2_thr_f32, double dist2_thr, FoeScratch s, double* foe,
+                         int32_t* box_acc, unsigned long long* max_phi_bits)
 {
-    hipLaunchKernelGGL(k_foe_candidates<FlowT>, dim3(B), dim3(1024), 0, st, flow, derot, samples, W, H, N, mag2_thr, mag2_thr_f32, s);
-    hipLaunchKernelGGL(k_ransac, dim3((N + 255) / 256, B), dim3(256), sizeof(double2) * (size_t)N, st, s, N, dist2_thr);
-    hipLaunchKernelGGL(k_foe_finalize, dim3((B + 63) / 64), dim3(64), 0, st, s, N, B, foe);
+    hipLaunchKernelGGL(k_foe_candidates<FlowT>, dim3(B), dim3(1024), 0, st, flow, derot, samples, W, H, N, mag2_thr, mag2_thr_f32, s,
+                       box_acc, max_phi_bits);
+    hipLaunchKernelGGL(k_ransac, dim3((N + 15) / 16, B), dim3(256), 0, st, s, N, dist2_thr, foe);
 }
 void launch_foe_f32(hipStream_t st, const float* flow, const DerotParams* derot, const uint32_t* samples, int B, int W, int H,
-                    int N, double mag2_thr, float mag2_thr_f32, double dist2_thr, FoeScratch s, double* foe)
+                    int N, double mag2_thr, float mag2_thr_f32, double dist2_thr, FoeScratch s, double* foe, int32_t* box_acc,
+                    unsigned long long* max_phi_bits)
 {
-    launch_foe_t<float>(st, flow, derot, samples, B, W, H, N, mag2_thr, mag2_thr_f32, dist2_thr, s, foe);
+    launch_foe_t<float>(st, flow, derot, samples, B, W, H, N, mag2_thr, mag2_thr_f32, dist2_thr, s, foe, box_acc, max_phi_bits);
 }
 void launch_foe_f64(hipStream_t st, const double* flow, const uint32_t* samples, int B, int W, int H, int N, double mag2_thr,
-                    double dist2_thr, FoeScratch s, double* foe)
+                    double dist2_thr, FoeScratch s, double* foe, int32_t* box_acc, unsigned long long* max_phi_bits)
 {
-    launch_foe_t<double>(st, flow, nullptr, samples, B, W, H, N, mag2_thr, 0.f, dist2_thr, s, foe);
+    launch_foe_t<double>(st, flow, nullptr, samples, B, W, H, N, mag2_thr, 0.f, dist2_thr, s, foe, box_acc, max_phi_bits);
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // phi + both threshold masks + box extents + max(phi), one pass over the flow.  Workgroup = 4 rows x 256 columns,
 // lane-contiguous float2/double2 loads; box extents and max(phi) are reduced per wave, then one atomic per wave.
 // ------------------------------------------------------------------------------------------------------------
-__global__ void k_box_init(int32_t* box_acc, unsigned long long* max_phi_bits, int B)
+__global__ void k_box_init(int32_t* box_acc, unsigned long long* max_phi_bits, unsigned* done, int B)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     box_acc[4 * b] = INT_MAX; box_acc[4 * b + 1] = INT_MAX; box_acc[4 * b + 2] = -1; box_acc[4 * b + 3] = -1;
     if (max_phi_bits) max_phi_bits[b] = 0ull;
+    if (done) done[2 * b + 1] = 0u;
 }
-void launch_box_init(hipStream_t st, int32_t* box_acc, unsigned long long* max_phi_bits, int B)
+// (the fused chain needs no such launch: k_foe_candidates initialises its pair's accumulators)
+void launch_box_init(hipStream_t st, int32_t* box_acc, unsigned long long* max_phi_bits, unsigned* done, int B)
 {
-    hipLaunchKernelGGL(k_box_init, dim3((B + 63) / 64), dim3(64), 0, st, box_acc, max_phi_bits, B);
+    hipLaunchKernelGGL(k_box_init, dim3((B + 63) / 64), dim3(64), 0, st, box_acc, max_phi_bits, done, B);
 }
 
 // Box extents of one wave -> the pair's accumulators.  The accumulators only ever grow, so a (possibly stale) read that
@@ -243,10 +267,13 @@ static __device__ __forceinline__ void wave_box_commit(int x0, int y0, int x1, i
         const int c1 = __hip_atomic_load(&acc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int c2 = __hip_atomic_load(&acc[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int c3 = __hip_atomic_load(&acc[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (x0 < c0) atomicMin(&acc[0], x0);
-        if (y0 < c1) atomicMin(&acc[1], y0);
-        if (x1 > c2) atomicMax(&acc[2], x1);
-        if (y1 > c3) atomicMax(&acc[3], y1);
+        // returning atomics whose results are waited for: when the workgroup draws its ticket (k_phi_mask's tail) they have been performed
+        int seen = 0;
+        if (x0 < c0) seen |= atomicMin(&acc[0], x0);
+        if (y0 < c1) seen |= atomicMin(&acc[1], y0);
+        if (x1 > c2) seen |= atomicMax(&acc[2], x1);
+        if (y1 > c3) seen |= atomicMax(&acc[3], y1);
+        asm volatile("s_waitcnt vmcnt(0)" ::"v"(seen) : "memory");
     }
 }
 
@@ -365,7 +392,9 @@ __global__ __launch_bounds__(256) void k_phi_mask(const FlowT* __restrict__ flow
                                                   const double* __restrict__ foe, const uint8_t* __restrict__ sky, int W, int H,
                                                   mav_thr_params thr, PhiScreen scr, double* __restrict__ phi_out,
                                                   uint8_t* __restrict__ mfix, uint8_t* __restrict__ mdyn,
-                                                  int32_t* __restrict__ box_acc, unsigned long long* __restrict__ max_phi_bits)
+                                                  int32_t* __restrict__ box_acc, unsigned long long* __restrict__ max_phi_bits,
+                                                  unsigned* __restrict__ done, mav_result* __restrict__ results,
+                                                  int32_t* __restrict__ box_out)
 {
     const int b = blockIdx.z;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -478,17 +507,39 @@ __global__ __launch_bounds__(256) void k_phi_mask(const FlowT* __restrict__ flow
         if (lane == 0 && bits > __hip_atomic_load(&max_phi_bits[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
             atomicMax(&max_phi_bits[b], bits);
     }
+    // The pair's record (box + FoE; im_helpers.py:55-84 gives -1 for an empty mask) is written by the workgroup that draws the
+    // pair's last ticket: every workgroup's box atomics have returned (wave_box_commit waits for them) before its ticket is drawn,
+    // and the accumulators are read with agent-scope loads.  No separate finalize launch.
+    if (done) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned ticket = atomicAdd(&done[2 * b + 1], 1u);
+            if (ticket == gridDim.x * gridDim.y - 1) {
+                int x0 = __hip_atomic_load(&box_acc[4 * b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int y0 = __hip_atomic_load(&box_acc[4 * b + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int x1 = __hip_atomic_load(&box_acc[4 * b + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int y1 = __hip_atomic_load(&box_acc[4 * b + 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (x1 < 0) { x0 = y0 = x1 = y1 = -1; }
+                if (results) {
+                    results[b].box[0] = x0; results[b].box[1] = y0; results[b].box[2] = x1; results[b].box[3] = y1;
+                    results[b].foe[0] = foex; results[b].foe[1] = foey;
+                }
+                if (box_out) { box_out[4 * b] = x0; box_out[4 * b + 1] = y0; box_out[4 * b + 2] = x1; box_out[4 * b + 3] = y1; }
+                __hip_atomic_store(&done[2 * b + 1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
 }
 
 // The screen is usable when neither phi nor max(phi) is requested and the thresholds are in the regime where
 // "lo" (phi < dyn_a - (dyn_b + dyn_c/mag)) can never fire, the fixed threshold lies in (0, 80) degrees and the dynamic one is >= 0.
-static PhiScreen phi_screen(const mav_thr_params& t, const double* phi, const unsigned long long* max_phi_bits)
+static PhiScreen phi_screen(const mav_thr_params& t, const double* phi, const unsigned long long* max_phi_bits, bool screen_on)
 {
     PhiScreen s{};
     const bool ok = !phi && !max_phi_bits && t.fixed_deg > 0.0 && t.fixed_deg < 80.0 && t.dyn_a - t.dyn_b <= 0.0 &&
                     t.dyn_c >= 0.0 && t.dyn_a + t.dyn_b >= 0.0 && t.fixed_min_mag > 1e-3 && t.dyn_min_mag > 1e-3 &&
                     t.fixed_min_mag < 1e6 && t.dyn_min_mag < 1e6 && t.dyn_c < 1e6 && t.dyn_a + t.dyn_b < 1e3;
-    { const char* e = getenv("MAVFLOW_NO_SCREEN"); s.enabled = ok && !(e && atoi(e) != 0); }
+    s.enabled = ok && screen_on;
     s.tan_fixed = ok ? (float)tan(t.fixed_deg * 3.141592653589793238462643383279502884 / 180.0) : 0.f;
     s.margin_fixed = MAV_SCREEN_TAN_MARGIN * (1.f + s.tan_fixed);
     s.fmm2 = (float)(t.fixed_min_mag * t.fixed_min_mag);
@@ -501,16 +552,15 @@ static PhiScreen phi_screen(const mav_thr_params& t, const double* phi, const un
 template <typename FlowT>
 static void launch_phi_mask_t(hipStream_t st, const FlowT* flow, const DerotParams* derot, const double* foe, const uint8_t* sky,
                               int B, int W, int H, mav_thr_params thr, double* phi, uint8_t* mask_fixed, uint8_t* mask_dyn,
-                              int32_t* box_acc, unsigned long long* max_phi_bits)
+                              int32_t* box_acc, unsigned long long* max_phi_bits, const PhiLaunch& pl)
 {
-    const PhiScreen scr = phi_screen(thr, phi, max_phi_bits);
+    const PhiScreen scr = phi_screen(thr, phi, max_phi_bits, pl.screen);
     const bool vec = W % 4 == 0 && (((uintptr_t)sky | (uintptr_t)mask_fixed | (uintptr_t)mask_dyn) & 3) == 0;
     // Blocks of 16 rows per workgroup: enough that the whole launch stays near 4096 workgroups.  With one block each (34 816
     // workgroups at 1080p x 64 pairs) the kernel is bound by the rate at which waves can be launched, not by its bytes:
-    // measured 0.55 ms, against 0.47 / 0.36 / 0.32 / 0.31 ms with 2 / 4 / 8 / 17 blocks per workgroup (MAVFLOW_PHI_YLOOP overrides).
+    // measured 0.55 ms, against 0.47 / 0.36 / 0.32 / 0.31 ms with 2 / 4 / 8 / 17 blocks per workgroup (option "phi_yloop" overrides).
     const int nby = (H + 15) / 16, gx = vec ? (W / 4 + 63) / 64 : (W + 63) / 64;
-    int yloop = 0;
-    if (const char* e = getenv("MAVFLOW_PHI_YLOOP")) yloop = atoi(e);
+    int yloop = pl.yloop;
     if (yloop < 1) {
         const int want = 4096 / (gx * B > 0 ? gx * B : 1);
         yloop = want > 0 ? (nby + want - 1) / want : nby;
@@ -518,19 +568,20 @@ static void launch_phi_mask_t(hipStream_t st, const FlowT* flow, const DerotPara
     const dim3 grid(gx, (nby + yloop - 1) / yloop, B);
     auto k = vec ? (derot ? k_phi_mask<FlowT, 4, true> : k_phi_mask<FlowT, 4, false>)
                  : (derot ? k_phi_mask<FlowT, 1, true> : k_phi_mask<FlowT, 1, false>);
-    hipLaunchKernelGGL(k, grid, dim3(256), 0, st, flow, derot, foe, sky, W, H, thr, scr, phi, mask_fixed, mask_dyn, box_acc, max_phi_bits);
+    hipLaunchKernelGGL(k, grid, dim3(256), 0, st, flow, derot, foe, sky, W, H, thr, scr, phi, mask_fixed, mask_dyn, box_acc, max_phi_bits,
+                       (pl.results || pl.box_out) ? pl.done : (unsigned*)nullptr, pl.results, pl.box_out);
 }
 void launch_phi_mask_f32(hipStream_t st, const float* flow, const DerotParams* derot, const double* foe, const uint8_t* sky,
                          int B, int W, int H, mav_thr_params thr, double* phi, uint8_t* mask_fixed, uint8_t* mask_dyn,
-                         int32_t* box_acc, unsigned long long* max_phi_bits)
+                         int32_t* box_acc, unsigned long long* max_phi_bits, const PhiLaunch& pl)
 {
-    launch_phi_mask_t<float>(st, flow, derot, foe, sky, B, W, H, thr, phi, mask_fixed, mask_dyn, box_acc, max_phi_bits);
+    launch_phi_mask_t<float>(st, flow, derot, foe, sky, B, W, H, thr, phi, mask_fixed, mask_dyn, box_acc, max_phi_bits, pl);
 }
 void launch_phi_mask_f64(hipStream_t st, const double* flow, const double* foe, const uint8_t* sky, int B, int W, int H,
                          mav_thr_params thr, double* phi, uint8_t* mask_fixed, uint8_t* mask_dyn, int32_t* box_acc,
-                         unsigned long long* max_phi_bits)
+                         unsigned long long* max_phi_bits, const PhiLaunch& pl)
 {
-    launch_phi_mask_t<double>(st, flow, nullptr, foe, sky, B, W, H, thr, phi, mask_fixed, mask_dyn, box_acc, max_phi_bits);
+    launch_phi_mask_t<double>(st, flow, nullptr, foe, sky, B, W, H, thr, phi, mask_fixed, mask_dyn, box_acc, max_phi_bits, pl);
 }
 
 __global__ void k_finalize(const int32_t* __restrict__ box_acc, const double* __restrict__ foe, int B, mav_result* __restrict__ res,
@@ -545,10 +596,6 @@ __global__ void k_finalize(const int32_t* __restrict__ box_acc, const double* __
         res[b].foe[0] = foe[2 * b]; res[b].foe[1] = foe[2 * b + 1];
     }
     if (box_only) { box_only[4 * b] = x0; box_only[4 * b + 1] = y0; box_only[4 * b + 2] = x1; box_only[4 * b + 3] = y1; }
-}
-void launch_finalize(hipStream_t st, const int32_t* box_acc, const double* foe, int B, mav_result* results)
-{
-    hipLaunchKernelGGL(k_finalize, dim3((B + 63) / 64), dim3(64), 0, st, box_acc, foe, B, results, (int32_t*)nullptr);
 }
 void launch_box_finalize(hipStream_t st, const int32_t* box_acc, int B, int32_t* box)
 {
@@ -695,12 +742,12 @@ __global__ void k_set_count(FoeScratch sc, int M)
 {
     sc.count[0] = M;
     sc.best_key[0] = 0ull;
+    sc.done[0] = 0u;
 }
 void launch_ransac_only(hipStream_t st, FoeScratch s, int M, int N, double dist2_thr, double* foe)
 {
     hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, st, s, M);
-    if (M > 0) hipLaunchKernelGGL(k_ransac, dim3((M + 255) / 256, 1), dim3(256), sizeof(double2) * (size_t)N, st, s, N, dist2_thr);
-    hipLaunchKernelGGL(k_foe_finalize, dim3(1), dim3(64), 0, st, s, N, 1, foe);
+    hipLaunchKernelGGL(k_ransac, dim3(((M > 0 ? M : 1) + 15) / 16, 1), dim3(256), 0, st, s, N, dist2_thr, foe);
 }
 
 // DerotParams from device-resident omega (B,3) and dt (B, nullable = 1): sx = w*dt/2, sy = h*dt/2 (detector.py:101-102).

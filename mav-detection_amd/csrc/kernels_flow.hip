@@ -9,8 +9,6 @@
 // The path is HBM/LDS-bound stencil work: no MFMA.
 #include "mavflow_internal.h"
 
-#include <stdlib.h>
-
 static __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -41,9 +39,8 @@ static __device__ __forceinline__ bool tile_of_block(const TileMap& tm, int* s, 
     *s = img; *ty = row + tm.ty0; *tx = x_base + tr - row * sw;
     return true;
 }
-static int g_strip_override = -1;                                // MAVFLOW_STRIP: tuning experiments only
-// rows [ty0, ty1) of the tile grid only (a band of the image); ty1 < 0 = all rows
-static TileMap make_tile_map(int w, int h, int G, int tile_w, int tile_h, int ty0 = 0, int ty1 = -1)
+// rows [ty0, ty1) of the tile grid only (a band of the image); ty1 < 0 = all rows.  strip > 0: strips of that many tiles (option "strip").
+static TileMap make_tile_map(int w, int h, int G, int tile_w, int tile_h, int ty0 = 0, int ty1 = -1, int strip = 0)
 {
     TileMap tm;
     tm.xcd = 1;
@@ -54,9 +51,8 @@ static TileMap make_tile_map(int w, int h, int G, int tile_w, int tile_h, int ty
     tm.tiles_y = tm.tiles_y > tm.ty0 ? tm.tiles_y - tm.ty0 : 0;
     tm.per_img = tm.tiles_x * tm.tiles_y;
     tm.n_tiles = tm.per_img * G;
-    if (g_strip_override < 0) { const char* e = getenv("MAVFLOW_STRIP"); g_strip_override = e ? atoi(e) : 0; }
     int sw = tm.tiles_x;
-    if (g_strip_override > 0) sw = g_strip_override < tm.tiles_x ? g_strip_override : tm.tiles_x;
+    if (strip > 0) sw = strip < tm.tiles_x ? strip : tm.tiles_x;
     else if (tm.tiles_x > 40) { const int ns = (tm.tiles_x + 29) / 30; sw = (tm.tiles_x + ns - 1) / ns; }
     tm.strip_w = sw;
     return tm;
@@ -110,15 +106,17 @@ static __device__ __forceinline__ int reflect101d(int p, int len)
     return p;
 }
 
-__global__ __launch_bounds__(256) void k_blur_resize_h(const uint8_t* __restrict__ img, size_t img_stride, int W, int H, int w,
-                                                       BlurParams bp, float* __restrict__ tmp, size_t tmp_stride)
+// Image z of a launch over two runs of images (the `prev` frames and the `next` frames of a group): z < split comes from run a.
+static __device__ __forceinline__ const uint8_t* image_of(const uint8_t* a, const uint8_t* b, int split, size_t stride, int z)
 {
-    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 4;
-    if (dx >= w || y0 >= H) return;
-    const uint8_t* base = img + (size_t)blockIdx.z * img_stride;
-    int s0; float f;
-    resize_coord(dx, W, w, bp.scale_x, &s0, &f);
+    return z < split ? a + (size_t)z * stride : b + (size_t)(z - split) * stride;
+}
+
+// Horizontal pass at destination column (s0, f) for the four source rows y0 .. y0 + 3 (clamped to the image): the ONE spelling of
+// this arithmetic, shared by the two-pass and the fused kernel so that both give the same bits.
+static __device__ __forceinline__ void blur_h4(const uint8_t* __restrict__ base, int W, int H, int y0, int s0, float f,
+                                               const BlurParams& bp, float out[4])
+{
     const int r = bp.ksize >> 1;
     const int s1 = s0 + 1 < W ? s0 + 1 : s0;
     const uint8_t* rows[4];
@@ -138,8 +136,8 @@ __global__ __launch_bounds__(256) void k_blur_resize_h(const uint8_t* __restrict
                 const float g = bp.g[t];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    b0[k] += g * (float)px[k][t];
-                    b1[k] += g * (float)px[k][t + 1];
+                    b0[k] = fmaf(g, (float)px[k][t], b0[k]);
+                    b1[k] = fmaf(g, (float)px[k][t + 1], b1[k]);
                 }
             }
         } else {
@@ -178,8 +176,8 @@ __global__ __launch_bounds__(256) void k_blur_resize_h(const uint8_t* __restrict
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
                             const float nxt = (float)((cur[k] >> (8 * b)) & 0xffu);
-                            b0[k] += g * prev[k];
-                            b1[k] += g * nxt;
+                            b0[k] = fmaf(g, prev[k], b0[k]);
+                            b1[k] = fmaf(g, nxt, b1[k]);
                             prev[k] = nxt;
                         }
                     }
@@ -191,14 +189,65 @@ __global__ __launch_bounds__(256) void k_blur_resize_h(const uint8_t* __restrict
             const float g = bp.g[t];
             const int c0 = reflect101d(s0 - r + t, W), c1 = reflect101d(s1 - r + t, W);
 #pragma unroll
-            for (int k = 0; k < 4; k++) { b0[k] += g * (float)rows[k][c0]; b1[k] += g * (float)rows[k][c1]; }
+            for (int k = 0; k < 4; k++) { b0[k] = fmaf(g, (float)rows[k][c0], b0[k]); b1[k] = fmaf(g, (float)rows[k][c1], b1[k]); }
         }
     }
-    float* dst = tmp + (size_t)blockIdx.z * tmp_stride + dx;
     const float a0 = 1.f - f;
 #pragma unroll
+    for (int k = 0; k < 4; k++) out[k] = fmaf(b1[k], f, b0[k] * a0);
+}
+
+// Vertical pass at destination row (s0, f): row(y) = the horizontal pass's value at source row y of this thread's column.
+template <typename RowFn>
+static __device__ __forceinline__ float blur_v1(RowFn row, int H, int s0, float f, const BlurParams& bp)
+{
+    const int r = bp.ksize >> 1;
+    const int s1 = s0 + 1 < H ? s0 + 1 : s0;
+    float b0 = 0.f, b1 = 0.f;
+    if (s0 - r >= 0 && s0 + 1 + r < H) {
+        if (bp.ksize == 5) {                               // the six rows of the thread requested together
+            float px[6];
+#pragma unroll
+            for (int t = 0; t < 6; t++) px[t] = row(s0 - 2 + t);
+#pragma unroll
+            for (int t = 0; t < 5; t++) { b0 = fmaf(bp.g[t], px[t], b0); b1 = fmaf(bp.g[t], px[t + 1], b1); }
+        } else {
+            float prev = row(s0 - r);
+#pragma unroll 8
+            for (int t = 0; t < bp.ksize; t++) {
+                const float g = bp.g[t];
+                const float nxt = row(s0 - r + t + 1);
+                b0 = fmaf(g, prev, b0);
+                b1 = fmaf(g, nxt, b1);
+                prev = nxt;
+            }
+        }
+    } else {
+        for (int t = 0; t < bp.ksize; t++) {
+            const float g = bp.g[t];
+            b0 = fmaf(g, row(reflect101d(s0 - r + t, H)), b0);
+            b1 = fmaf(g, row(reflect101d(s1 - r + t, H)), b1);
+        }
+    }
+    return fmaf(b1, f, b0 * (1.f - f));
+}
+
+__global__ __launch_bounds__(256) void k_blur_resize_h(const uint8_t* __restrict__ img, const uint8_t* __restrict__ img2, int split,
+                                                       size_t img_stride, int W, int H, int w, BlurParams bp,
+                                                       float* __restrict__ tmp, size_t tmp_stride)
+{
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 4;
+    if (dx >= w || y0 >= H) return;
+    const uint8_t* base = image_of(img, img2, split, img_stride, blockIdx.z);
+    int s0; float f;
+    resize_coord(dx, W, w, bp.scale_x, &s0, &f);
+    float o[4];
+    blur_h4(base, W, H, y0, s0, f, bp, o);
+    float* dst = tmp + (size_t)blockIdx.z * tmp_stride + dx;
+#pragma unroll
     for (int k = 0; k < 4; k++)
-        if (y0 + k < H) dst[(size_t)(y0 + k) * w] = b0[k] * a0 + b1[k] * f;
+        if (y0 + k < H) dst[(size_t)(y0 + k) * w] = o[k];
 }
 
 __global__ __launch_bounds__(256) void k_blur_resize_v(const float* __restrict__ tmp, size_t tmp_stride, int H, int w, int h,
@@ -210,47 +259,69 @@ __global__ __launch_bounds__(256) void k_blur_resize_v(const float* __restrict__
     const float* src = tmp + (size_t)blockIdx.z * tmp_stride + dx;
     int s0; float f;
     resize_coord(dy, H, h, bp.scale_y, &s0, &f);
+    out[(size_t)blockIdx.z * out_stride + (size_t)dy * w + dx] = blur_v1([&](int y) { return src[(size_t)y * w]; }, H, s0, f, bp);
+}
+
+// Both passes in ONE kernel for the layers whose Gaussian is short (ksize <= 13: layer 1 of the reference's preset, layers 1 - 2
+// of the 4K / 5-layer one): a workgroup owns a 64 x FB_TH tile of the layer, runs the horizontal pass over the source rows the
+// tile's vertical pass will read -- [s0(first row) - r, s0(last row) + 1 + r] clamped to the image; a reflected row index always
+// falls inside that range -- into LDS (rows x 64 f32), and filters / resamples vertically from there.  The H x w f32 scratch of
+// the two-pass form (written once, read ~(ksize + 1) h / H times: 2.95x the stage's algorithmic bytes) never exists.  Same
+// functions, same tap order: bit-identical to the two-pass form (tests/test_gpu_flow.py).  The rows two vertically adjacent
+// tiles share (2r + 1 of ~40 at scale 0.4) are filtered twice.
+#define FB_TH 16
+__global__ __launch_bounds__(256) void k_blur_resize_fused(const uint8_t* __restrict__ img, const uint8_t* __restrict__ img2, int split,
+                                                           size_t img_stride, int W, int H, int w, int h, BlurParams bp,
+                                                           float* __restrict__ out, size_t out_stride, int rows_cap)
+{
+    extern __shared__ __attribute__((aligned(16))) float hrows[];       // [rows_cap][64]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int dx = blockIdx.x * 64 + lane, dxc = min(dx, w - 1);
+    const int dy0 = blockIdx.y * FB_TH, dy1 = min(dy0 + FB_TH, h) - 1;
+    const uint8_t* base = image_of(img, img2, split, img_stride, blockIdx.z);
     const int r = bp.ksize >> 1;
-    const int s1 = s0 + 1 < H ? s0 + 1 : s0;
-    float b0 = 0.f, b1 = 0.f;
-    if (s0 - r >= 0 && s0 + 1 + r < H) {
-        if (bp.ksize == 5) {                               // the six rows of the thread requested together
-            float px[6];
+    int sa, sb; float fa, fb;
+    resize_coord(dy0, H, h, bp.scale_y, &sa, &fa);
+    resize_coord(dy1, H, h, bp.scale_y, &sb, &fb);
+    const int ylo = max(sa - r, 0), yhi = min(sb + 1 + r, H - 1);
+    const int n_rows = min(yhi - ylo + 1, rows_cap);                  // (the host sized rows_cap for the worst tile)
+    int s0; float f;
+    resize_coord(dxc, W, w, bp.scale_x, &s0, &f);
+    for (int i = wv * 4; i < n_rows; i += 16) {
+        float o[4];
+        blur_h4(base, W, H, ylo + i, s0, f, bp, o);
 #pragma unroll
-            for (int t = 0; t < 6; t++) px[t] = src[(size_t)(s0 - 2 + t) * w];
-#pragma unroll
-            for (int t = 0; t < 5; t++) { b0 += bp.g[t] * px[t]; b1 += bp.g[t] * px[t + 1]; }
-        } else {
-            float prev = src[(size_t)(s0 - r) * w];
-#pragma unroll 8
-            for (int t = 0; t < bp.ksize; t++) {
-                const float g = bp.g[t];
-                const float nxt = src[(size_t)(s0 - r + t + 1) * w];
-                b0 += g * prev;
-                b1 += g * nxt;
-                prev = nxt;
-            }
-        }
-    } else {
-        for (int t = 0; t < bp.ksize; t++) {
-            const float g = bp.g[t];
-            b0 += g * src[(size_t)reflect101d(s0 - r + t, H) * w];
-            b1 += g * src[(size_t)reflect101d(s1 - r + t, H) * w];
-        }
+        for (int k = 0; k < 4; k++)
+            if (i + k < n_rows) hrows[(i + k) * 64 + lane] = o[k];
     }
-    out[(size_t)blockIdx.z * out_stride + (size_t)dy * w + dx] = b0 * (1.f - f) + b1 * f;
+    __syncthreads();
+    if (dx >= w) return;
+    const float* col = hrows + lane - ylo * 64;
+#pragma unroll
+    for (int j = 0; j < FB_TH / 4; j++) {
+        const int dy = dy0 + j * 4 + wv;
+        if (dy > dy1) break;
+        int t0; float tf;
+        resize_coord(dy, H, h, bp.scale_y, &t0, &tf);
+        out[(size_t)blockIdx.z * out_stride + (size_t)dy * w + dx] = blur_v1([&](int y) { return col[y * 64]; }, H, t0, tf, bp);
+    }
+}
+static int fused_blur_rows(int H, int h, int ksize) { return (int)((FB_TH - 1) * ((double)H / h)) + (ksize | 1) + 4; }
+bool blur_resize_is_fused(int W, int H, int w, int h, int ksize)
+{
+    return !(w == W && h == H) && ksize <= 13 && H > 2 * ksize && W > 2 * ksize && (size_t)fused_blur_rows(H, h, ksize) * 256 <= 48 * 1024;
 }
 
 // Layer 0 (scale 1, sigma 0 -> fixed kernel [1/4, 1/2, 1/4], BORDER_REFLECT_101): every product is exact in f32,
 // so this is bit-identical to OpenCV's row-then-column filter.  One thread = 4 consecutive pixels x 4 rows:
 // six aligned u32 row loads + the two neighbour bytes per row, float4 stores.
-__global__ __launch_bounds__(256) void k_blur3_u8(const uint8_t* __restrict__ img, size_t img_stride, int W, int H,
-                                                  float* __restrict__ out, size_t out_stride)
+__global__ __launch_bounds__(256) void k_blur3_u8(const uint8_t* __restrict__ img, const uint8_t* __restrict__ img2, int split,
+                                                  size_t img_stride, int W, int H, float* __restrict__ out, size_t out_stride)
 {
     const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
     const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 4;
     if (x >= W || y0 >= H) return;
-    const uint8_t* src = img + (size_t)blockIdx.z * img_stride;
+    const uint8_t* src = image_of(img, img2, split, img_stride, blockIdx.z);
     float* dst = out + (size_t)blockIdx.z * out_stride;
     const int xl = x == 0 ? 1 : x - 1;                    // reflect101
     const int xr = x + 4 >= W ? W - 2 : x + 4;
@@ -290,17 +361,37 @@ __global__ __launch_bounds__(256) void k_blur3_u8(const uint8_t* __restrict__ im
     }
 }
 
-void launch_blur_resize(hipStream_t st, const uint8_t* img, size_t img_stride, int G, int W, int H, int w, int h,
-                        BlurParams bp, float* tmp, size_t tmp_stride, float* out, size_t out_stride)
+// G images: the first `split` from run img, the rest from run img2 (both with stride img_stride); split >= G: one run.
+// two_pass: force the separable two-pass form through the tmp scratch (the stage hook compares the two forms).
+static bool blur3_fast_ok(const uint8_t* img, const uint8_t* img2, size_t img_stride, int W, int H, int w, int h, const BlurParams& bp,
+                          const float* out, size_t out_stride)
 {
-    if (w == W && h == H && bp.fixed3 && W % 4 == 0 && W >= 8 && H >= 2 && img_stride % 4 == 0 && out_stride % 4 == 0 &&
-        ((uintptr_t)img & 3) == 0 && ((uintptr_t)out & 15) == 0) {
+    return w == W && h == H && bp.fixed3 && W % 4 == 0 && W >= 8 && H >= 2 && img_stride % 4 == 0 && out_stride % 4 == 0 &&
+           ((uintptr_t)img & 3) == 0 && ((uintptr_t)img2 & 3) == 0 && ((uintptr_t)out & 15) == 0;
+}
+// true when launch_blur_resize (two_pass = false) will go through the tmp scratch for these operands
+bool blur_resize_needs_tmp(const uint8_t* img, const uint8_t* img2, size_t img_stride, int W, int H, int w, int h, BlurParams bp,
+                           const float* out, size_t out_stride)
+{
+    return !blur3_fast_ok(img, img2 ? img2 : img, img_stride, W, H, w, h, bp, out, out_stride) && !blur_resize_is_fused(W, H, w, h, bp.ksize);
+}
+void launch_blur_resize(hipStream_t st, const uint8_t* img, const uint8_t* img2, int split, size_t img_stride, int G, int W, int H, int w,
+                        int h, BlurParams bp, float* tmp, size_t tmp_stride, float* out, size_t out_stride, bool two_pass)
+{
+    if (!img2) { img2 = img; split = G; }
+    if (blur3_fast_ok(img, img2, img_stride, W, H, w, h, bp, out, out_stride)) {
         dim3 grid((W / 4 + 63) / 64, ((H + 3) / 4 + 3) / 4, G);
-        hipLaunchKernelGGL(k_blur3_u8, grid, dim3(256), 0, st, img, img_stride, W, H, out, out_stride);
+        hipLaunchKernelGGL(k_blur3_u8, grid, dim3(256), 0, st, img, img2, split, img_stride, W, H, out, out_stride);
         return;
     }
-    hipLaunchKernelGGL(k_blur_resize_h, dim3((w + 63) / 64, ((H + 3) / 4 + 3) / 4, G), dim3(256), 0, st, img, img_stride, W, H, w, bp,
-                       tmp, tmp_stride);
+    if (!two_pass && blur_resize_is_fused(W, H, w, h, bp.ksize)) {
+        const int rows = fused_blur_rows(H, h, bp.ksize);
+        hipLaunchKernelGGL(k_blur_resize_fused, dim3((w + 63) / 64, (h + FB_TH - 1) / FB_TH, G), dim3(256), (size_t)rows * 256, st, img, img2,
+                           split, img_stride, W, H, w, h, bp, out, out_stride, rows);
+        return;
+    }
+    hipLaunchKernelGGL(k_blur_resize_h, dim3((w + 63) / 64, ((H + 3) / 4 + 3) / 4, G), dim3(256), 0, st, img, img2, split, img_stride, W, H,
+                       w, bp, tmp, tmp_stride);
     hipLaunchKernelGGL(k_blur_resize_v, dim3((w + 63) / 64, (h + 3) / 4, G), dim3(256), 0, st, (const float*)tmp, tmp_stride, H, w, h,
                        bp, out, out_stride);
 }
@@ -920,149 +1011,6 @@ __global__ __launch_bounds__(256) void k_blur_iter_fast(const float* __restrict_
     STAMP_ADD(0, ts0, ts1); STAMP_ADD(1, ts1, ts2); STAMP_ADD(2, ts2, ts3); STAMP_ADD(4, ts3, ts4); STAMP_ADD(6, ts0, ts4); STAMP_ADD(7, 0ull, 1ull);
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// The sweep without an M array ("recompute" form).  The measured limit of k_blur_iter_fast is HBM bytes (80 B per pixel
-// and sweep, half of it M in / M' out), while its VALU sits at ~27 %.  M is a pointwise function of (R0, R1, flow), so
-// this kernel rebuilds it for the tile AND its 6-pixel halo (2.08x the UpdateMatrices arithmetic, served by L2 for the
-// halo) instead of storing and re-reading it: per pixel and sweep it moves R0 20 + R1 20 + flow-in 8 + flow-out 8 =
-// 56 B of HBM traffic, and the initial-M kernel of a layer disappears (the first sweep takes a zero / upsampled flow).
-//   phase 1  M for the 76 x 28 region -> LDS (5 planes): per pixel flow-in, R0, 2x2 R1 gather (two pixels in flight)
-//   phase 2  vertical sliding sums, float2 column pairs from LDS, written back in place (rows 0..15)
-//   phase 3  = phase B of k_blur_iter_fast: conflict-free b128 rows, horizontal sums, solve, flow -> HBM
-// LDS 43.8 KB -> 3 workgroups per CU.  Same algebra as the M-array form (results agree to f32 rounding noise).
-// ------------------------------------------------------------------------------------------------------------
-template <int M_T, int MODE>  // MODE 0: zero flow in, 1: upsampled coarse flow, 2: explicit flow (h, w, 2)
-__global__ __launch_bounds__(256) void k_sweep_rc(const float* __restrict__ fin, size_t fin_stride, int pw, int ph, float mul,
-                                                  double scale_x, double scale_y, const float* __restrict__ R0,
-                                                  const float* __restrict__ R1, size_t R_stride, int w, int h, TileMap tm,
-                                                  float scale, float* __restrict__ fout, size_t fout_stride)
-{
-    constexpr int EXT_X = FT_X + 2 * M_T;              // 76
-    constexpr int EXT_Y = FT_Y + 2 * M_T;              // 28
-    constexpr int WIN = 2 * M_T + 1;
-    constexpr int PITCH = (EXT_X + 3) & ~3;
-    constexpr int PLANE = EXT_Y * PITCH + (EXT_X - (EXT_Y * PITCH) % 64 + 128) % 64;   // = EXT_X (mod 64): float2 column pairs stay conflict-free across planes
-    constexpr int NPX = EXT_X * EXT_Y;                 // 2128
-    constexpr int NK = (NPX + 255) / 256;              // 9 region pixels per thread
-    static_assert(PLANE % 4 == 0 && EXT_X % 2 == 0, "alignment");
-    __shared__ __attribute__((aligned(16))) float ms[5 * PLANE];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wv = tid >> 6;
-    int s, tx, ty;
-    if (!tile_of_block(tm, &s, &tx, &ty)) return;
-    const int x0 = tx * FT_X, y0 = ty * FT_Y;
-    const size_t npx = (size_t)w * h;
-    const float* R0p = R0 + (size_t)s * R_stride;
-    const float* R1p = R1 + (size_t)s * R_stride;
-    const float* fi = fin + (size_t)s * fin_stride;
-
-    // this thread's region pixels: i = tid + 256 k; flow-in for all of them is requested up front
-    float2 f[NK];
-#pragma unroll
-    for (int k = 0; k < NK; k++) {
-        const int i = min(tid + 256 * k, NPX - 1);
-        const int lr = i / EXT_X, lc = i - lr * EXT_X;
-        const int cx = clampi(x0 - M_T + lc, 0, w - 1), cy = clampi(y0 - M_T + lr, 0, h - 1);
-        if (MODE == 0) f[k] = make_float2(0.f, 0.f);
-        else if (MODE == 1) f[k] = upsample_flow(fi, pw, ph, mul, scale_x, scale_y, cx, cy);
-        else f[k] = *(const float2*)(fi + ((size_t)cy * w + cx) * 2);
-    }
-#pragma unroll
-    for (int k0 = 0; k0 < NK; k0 += 2) {
-        GatherPx g[2];
-        float q[2][5];
-        int cxs[2], cys[2], off[2];
-        bool val[2];
-#pragma unroll
-        for (int jj = 0; jj < 2; jj++) {
-            const int k = k0 + jj < NK ? k0 + jj : NK - 1;
-            const int iraw = tid + 256 * (k0 + jj);
-            val[jj] = (k0 + jj < NK) && iraw < NPX;
-            const int i = min(tid + 256 * k, NPX - 1);
-            const int lr = i / EXT_X, lc = i - lr * EXT_X;
-            cxs[jj] = clampi(x0 - M_T + lc, 0, w - 1);
-            cys[jj] = clampi(y0 - M_T + lr, 0, h - 1);
-            off[jj] = lr * PITCH + lc;
-            const size_t o = (size_t)cys[jj] * w + cxs[jj];
-#pragma unroll
-            for (int c = 0; c < 5; c++) q[jj][c] = R0p[c * npx + o];
-            gather_issue(R1p, npx, w, h, cxs[jj], cys[jj], f[k].x, f[k].y, g[jj]);
-        }
-#pragma unroll
-        for (int jj = 0; jj < 2; jj++) {
-            const int k = k0 + jj < NK ? k0 + jj : NK - 1;
-            float o5[5];
-            update_finish(q[jj], g[jj], w, h, cxs[jj], cys[jj], f[k].x, f[k].y, o5);
-            if (val[jj]) {
-#pragma unroll
-                for (int c = 0; c < 5; c++) ms[c * PLANE + off[jj]] = o5[c];
-            }
-        }
-    }
-    __syncthreads();
-
-    {
-        constexpr int NP = EXT_X / 2;
-        for (int t = tid; t < 5 * NP; t += 256) {
-            const int c = t / NP, pr = t - c * NP;
-            float* col = ms + c * PLANE + 2 * pr;
-            float2 v[EXT_Y];
-#pragma unroll
-            for (int i = 0; i < EXT_Y; i++) v[i] = *(const float2*)(col + i * PITCH);
-            float sx = 0.f, sy = 0.f;
-#pragma unroll
-            for (int i = 0; i < WIN; i++) { sx += v[i].x; sy += v[i].y; }
-            *(float2*)col = make_float2(sx, sy);
-#pragma unroll
-            for (int y = 1; y < FT_Y; y++) {
-                sx += v[y + WIN - 1].x - v[y - 1].x;
-                sy += v[y + WIN - 1].y - v[y - 1].y;
-                *(float2*)(col + y * PITCH) = make_float2(sx, sy);
-            }
-        }
-    }
-    __syncthreads();
-
-    const int quad = (lane & 31) >> 2;
-    const int grp = (lane >> 5) * 2 + ((quad == 1 || quad == 2 || quad == 4 || quad == 7) ? 1 : 0);
-    const int qpos = (quad == 0 || quad == 1) ? 0 : ((quad == 3 || quad == 2) ? 1 : ((quad == 5 || quad == 4) ? 2 : 3));
-    const int pos = qpos * 4 + (lane & 3);
-    const int ly = wv * 4 + grp;
-    const int lx0 = pos * 4;
-    const int gx = x0 + lx0, gy = y0 + ly;
-    float S[5][4];
-#pragma unroll
-    for (int c = 0; c < 5; c++) {
-        const float4* p = (const float4*)(ms + c * PLANE + ly * PITCH + lx0);
-        constexpr int NV = (4 + 2 * M_T + 3) / 4;
-        float ff[4 * NV];
-#pragma unroll
-        for (int k = 0; k < NV; k++) {
-            const float4 t4 = p[k];
-            ff[4 * k] = t4.x; ff[4 * k + 1] = t4.y; ff[4 * k + 2] = t4.z; ff[4 * k + 3] = t4.w;
-        }
-        float a = 0.f;
-#pragma unroll
-        for (int k = 0; k < WIN; k++) a += ff[k];
-        S[c][0] = a;
-#pragma unroll
-        for (int j = 1; j < 4; j++) {
-            a += ff[j + WIN - 1] - ff[j - 1];
-            S[c][j] = a;
-        }
-    }
-    if (gx < w && gy < h) {
-        float u[4], v[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            solve_px(S[0][j] * scale, S[1][j] * scale, S[2][j] * scale, S[3][j] * scale, S[4][j] * scale, &u[j], &v[j]);
-        float* fo = fout + (size_t)s * fout_stride + ((size_t)gy * w + gx) * 2;
-        *(float4*)fo = make_float4(u[0], v[0], u[1], v[1]);
-        *(float4*)(fo + 4) = make_float4(u[2], v[2], u[3], v[3]);
-    }
-}
-
-
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 int blur_iter_tile_rows(int h) { return (h + FT_Y - 1) / FT_Y; }
 static bool blur_iter_vec_ok(int w, size_t M_stride, size_t R_stride, size_t f_stride, const void* M_in, const void* M_out, const void* R0,
@@ -1080,7 +1028,7 @@ bool blur_iter_bands_ok(int w, int winsize, size_t M_stride, size_t R_stride, si
 // tile rows [ty0, ty1) only (ty1 < 0: the whole layer).  Band launches exist for the fast form only (blur_iter_bands_ok).
 void launch_blur_iter(hipStream_t st, const float* M_in, float* M_out, size_t M_stride, const float* R0, const float* R1,
                       size_t R_stride, int G, int w, int h, int winsize, int do_update, int store_flow, float* flow, size_t f_stride,
-                      int ty0, int ty1)
+                      int ty0, int ty1, int strip)
 {
     int ext, pitch, plane;
     const int m = winsize / 2;
@@ -1088,14 +1036,14 @@ void launch_blur_iter(hipStream_t st, const float* M_in, float* M_out, size_t M_
     dim3 grid((w + MAV_TILE - 1) / MAV_TILE, (h + MAV_TILE - 1) / MAV_TILE, G);
     const bool vec_ok = blur_iter_vec_ok(w, M_stride, R_stride, f_stride, M_in, M_out, R0, R1, flow);
     if (m == 6 && vec_ok) {
-        const TileMap tm = make_tile_map(w, h, G, FT_X, FT_Y, ty0, ty1);
+        const TileMap tm = make_tile_map(w, h, G, FT_X, FT_Y, ty0, ty1, strip);
         if (tm.n_tiles == 0) return;
         hipLaunchKernelGGL(k_blur_iter_fast<6>, dim3(tile_grid(tm)), dim3(256), 0, st, M_in, M_out, M_stride, R0, R1, R_stride, w, h,
                            tm, scale, do_update, store_flow, flow, f_stride);
         return;
     }
     if (m == 6 && f_stride % 2 == 0 && ((uintptr_t)flow & 7) == 0) {    // any width / alignment: relaxed form of the same kernel
-        const TileMap tm = make_tile_map(w, h, G, FT_X, FT_Y);
+        const TileMap tm = make_tile_map(w, h, G, FT_X, FT_Y, 0, -1, strip);
         hipLaunchKernelGGL((k_blur_iter_fast<6, false>), dim3(tile_grid(tm)), dim3(256), 0, st, M_in, M_out, M_stride, R0, R1, R_stride,
                            w, h, tm, scale, do_update, store_flow, flow, f_stride);
         return;
@@ -1118,28 +1066,4 @@ const char* blur_iter_prepare(int winsize)
     if (lds <= (size_t)64 * 1024) return nullptr;
     const hipError_t e = hipFuncSetAttribute((const void*)k_blur_iter_generic<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     return e == hipSuccess ? nullptr : hipGetErrorString(e);
-}
-
-// One recompute sweep.  mode 0: zero flow in; 1: fin = coarser layer's flow (ph x pw x 2), upsampled * mul; 2: fin = this
-// layer's flow.  Returns false when the fast form does not apply (caller falls back to the M-array kernels).
-bool launch_sweep_rc(hipStream_t st, int mode, const float* fin, size_t fin_stride, int pw, int ph, float mul, const float* R0,
-                     const float* R1, size_t R_stride, int G, int w, int h, int winsize, float* fout, size_t fout_stride)
-{
-    const bool ok = winsize / 2 == 6 && (w % 4 == 0) && (R_stride % 4 == 0) && (fout_stride % 4 == 0) && aligned16(R0) &&
-                    aligned16(R1) && aligned16(fout) && (mode == 0 || (fin && ((uintptr_t)fin & 7) == 0 && fin_stride % 2 == 0));
-    if (!ok) return false;
-    const float scale = (float)(1.0 / ((double)winsize * winsize));
-    const TileMap tm = make_tile_map(w, h, G, FT_X, FT_Y);
-    const dim3 nb(tile_grid(tm));
-    const double sx = pw > 0 ? (double)pw / w : 0.0, sy = ph > 0 ? (double)ph / h : 0.0;
-    if (mode == 0)
-        hipLaunchKernelGGL((k_sweep_rc<6, 0>), nb, dim3(256), 0, st, fin, fin_stride, pw, ph, mul, sx, sy, R0, R1, R_stride, w,
-                           h, tm, scale, fout, fout_stride);
-    else if (mode == 1)
-        hipLaunchKernelGGL((k_sweep_rc<6, 1>), nb, dim3(256), 0, st, fin, fin_stride, pw, ph, mul, sx, sy, R0, R1, R_stride, w,
-                           h, tm, scale, fout, fout_stride);
-    else
-        hipLaunchKernelGGL((k_sweep_rc<6, 2>), nb, dim3(256), 0, st, fin, fin_stride, pw, ph, mul, sx, sy, R0, R1, R_stride, w,
-                           h, tm, scale, fout, fout_stride);
-    return true;
 }

@@ -185,7 +185,6 @@ struct ProfInterval { int kid; float t0, t1; };      // ms since the profile was
 
 struct mav_ctx {
     int device = 0, W = 0, H = 0, max_batch = 0, group = 0, group_fine = 1;
-    bool use_rc = false;         // option "recompute": sweeps rebuild M on the fly (k_sweep_rc) instead of storing it
     mav_fb_params fb;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;   // uploads that overlap the compute stream (mav_upload_async / mav_upload_fence)
@@ -197,30 +196,29 @@ struct mav_ctx {
     PolyCoef pc;
     // workspace (group slots)
     size_t n0 = 0, n1 = 0;
-    // Workspace of `group` slots, in TWO sets when a batch spans more than one group: while the finest layer's sweeps of
-    // group i run on the compute stream out of one set, group i + 1's pyramid and polynomial expansions are built on the
-    // preparation stream into the other (mav_farneback_dev).
+    // Workspace of `group` slots.
     struct WorkSet {
-        float *Htmp = nullptr;       // scratch of the separable blur+resize: group x H x (widest coarse layer)
-        float *I = nullptr, *R0 = nullptr, *R1 = nullptr, *Ma = nullptr, *Mb = nullptr, *fc[2] = {nullptr, nullptr};
-        // R0 and R1 are the two halves of ONE allocation (R1 = R0 + 5 n0 group).  r0 / r1 = where the expansions of the layer in
-        // work lie (layer_expansions): R0 / R1 for independent pairs; for a frame SEQUENCE (next = prev + one frame) the group's
-        // g + 1 frames are expanded once into slots 0 .. g of that allocation and pair s reads slots s and s + 1: r1 = R0 + 5 n0.
-        const float *r0 = nullptr, *r1 = nullptr;
-    } ws[2];
-    int nsets = 1;
-    bool pipeline = false;           // option "pipeline" (off: measured 2 % slower): prepare group i + 1 while group i sweeps
+        float *Htmp = nullptr;       // scratch of the two-pass blur+resize (layers whose Gaussian is too long for the fused kernel)
+        // R = R0 | R1 in ONE allocation (R1 = R0 + 5 n0 group): the expansions of the two frames of every pair.  For a frame SEQUENCE
+        // (next = prev + one frame) the group's g + 1 frames are expanded once into slots 0 .. g and pair s reads slots s and s + 1.
+        float *I = nullptr, *R = nullptr, *Ma = nullptr, *Mb = nullptr, *fc[2] = {nullptr, nullptr};
+    } ws;
     int bands = 1;                   // option "bands": the finest layer's sweeps in band-major order over this many skewed bands
     // option "pairs_in_flight" (1 or 2): the finest layer's per-pair work (initial M + sweeps) of a group alternates between the
     // compute stream and pair_stream, every pair band-major over bands of at most pif_band_mb of working set (layer_sweeps)
     int pairs_in_flight = 2, pif_band_mb = 86;
-    bool bands_set = false;          // "bands" given explicitly (option or MAVFLOW_BANDS): that many bands in either schedule
+    bool bands_set = false;          // "bands" given explicitly: that many bands in either schedule
+    bool group_fine_set = false;     // "group_fine" given explicitly
     hipStream_t pair_stream = nullptr;
     hipEvent_t pif_fork = nullptr, pif_join = nullptr;
     bool share_frames = true;        // option "share_frames": expand a frame once when next == prev + one frame (a frame sequence)
     int coarse_cache_mb = 220;       // coarse layers: pairs per launch capped so that the sweeps' working set stays below this (0 = no cap)
-    hipStream_t prep_stream = nullptr;
-    hipEvent_t prep_done[2] = {nullptr, nullptr}, fine_done[2] = {nullptr, nullptr}, call_begin = nullptr;
+    // tuning options that used to be environment variables (mav_set_option / mav_get_option; all reported by mav_schedule_info)
+    bool share_m = true;             // "share_m": one-stream schedule, every pair of a group ping-pongs M through the first slot's buffers
+    int coarse_half = 0;             // "coarse_half": pairs per launch of the coarse layers' two-stream schedule (0 = half the cache-sized count)
+    int strip = 0;                   // "strip": width in tiles of the column strips of the XCD-aware tile order (0 = automatic)
+    bool phi_screen = true;          // "phi_screen": the float32 screen in front of the exact phi / threshold arithmetic
+    int phi_yloop = 0;               // "phi_yloop": 16-row blocks per workgroup of the phi kernel (0 = automatic)
     size_t htmp_stride = 0;
     float* flow_ws = nullptr;      // lazily allocated (max_batch) when the caller does not want the flow
     // detection scratch (max_batch)
@@ -295,35 +293,36 @@ static void free_layer(Layer& l)
     l.g = nullptr;
 }
 
-// Workspace for `group` slots (two sets when max_batch spans more than one group).  The new buffers are allocated in full
-// before the old ones are released: when an allocation fails the context keeps its previous group and stays usable (the caller
-// sees MAV_ERR_OOM).
+// Workspace for `group` slots.  The new buffers are allocated in full before the old ones are released: when an allocation fails the
+// context keeps its previous group and stays usable (the caller sees MAV_ERR_OOM).
 static int alloc_group(mav_ctx* c, int group)
 {
-    const int nsets = (c->pipeline && c->max_batch > group) ? 2 : 1;
     const size_t g = (size_t)group, nc = 2 * (c->n1 ? c->n1 : 1);
-    // I and Htmp hold one frame more than the group: a frame sequence of g pairs has g + 1 frames.  R = R0 | R1 in one piece.
-    const size_t elems[7] = {c->n0 * (g + 1), 10 * c->n0 * g, 5 * c->n0 * g, 5 * c->n0 * g, nc * g, nc * g, c->htmp_stride * (g + 1)};
-    float* fresh[2][7] = {{nullptr}, {nullptr}};
-    for (int s = 0; s < nsets; s++)
-        for (int i = 0; i < 7; i++) {
-            const hipError_t e = hipMalloc(&fresh[s][i], sizeof(float) * elems[i]);
-            if (e != hipSuccess) {
-                for (int t = 0; t <= s; t++) for (int j = 0; j < 7; j++) if (fresh[t][j]) hipFree(fresh[t][j]);
-                (void)hipGetLastError();
-                return fail(e == hipErrorOutOfMemory ? MAV_ERR_OOM : MAV_ERR_HIP, "workspace for group %d (%zu bytes for buffer %d of set %d): %s",
-                            group, sizeof(float) * elems[i], i, s, hipGetErrorString(e));
-            }
+    // I / I2 hold the 2 g frames of a group (prev and next in one launch; a frame sequence of g pairs has g + 1 <= 2 g frames);
+    // Htmp holds g + 1 (the two-pass blur never runs over more frames per launch)
+    enum { NB = 7 };
+    const size_t elems[NB] = {c->n0 * 2 * g, 10 * c->n0 * g, 5 * c->n0 * g, 5 * c->n0 * g, nc * g, nc * g, c->htmp_stride * (g + 1)};
+    float* fresh[NB] = {nullptr};
+    for (int i = 0; i < NB; i++) {
+        const hipError_t e = hipMalloc(&fresh[i], sizeof(float) * elems[i]);
+        if (e != hipSuccess) {
+            for (int j = 0; j < NB; j++) if (fresh[j]) hipFree(fresh[j]);
+            (void)hipGetLastError();
+            return fail(e == hipErrorOutOfMemory ? MAV_ERR_OOM : MAV_ERR_HIP, "workspace for group %d (%zu bytes for buffer %d): %s", group,
+                        sizeof(float) * elems[i], i, hipGetErrorString(e));
         }
-    for (int s = 0; s < 2; s++) {
-        mav_ctx::WorkSet& w = c->ws[s];
-        float** bufs[7] = {&w.I, &w.R0, &w.Ma, &w.Mb, &w.fc[0], &w.fc[1], &w.Htmp};
-        for (int i = 0; i < 7; i++) { if (*bufs[i]) hipFree(*bufs[i]); *bufs[i] = s < nsets ? fresh[s][i] : nullptr; }
-        w.R1 = w.R0 ? w.R0 + 5 * c->n0 * g : nullptr;
-        w.r0 = w.R0; w.r1 = w.R1;
     }
+    mav_ctx::WorkSet& w = c->ws;
+    float** bufs[NB] = {&w.I, &w.R, &w.Ma, &w.Mb, &w.fc[0], &w.fc[1], &w.Htmp};
+    for (int i = 0; i < NB; i++) { if (*bufs[i]) hipFree(*bufs[i]); *bufs[i] = fresh[i]; }
     c->group = group;
-    c->nsets = nsets;
+    return MAV_OK;
+}
+
+static int sync_all_streams(mav_ctx* c)
+{
+    for (hipStream_t st : {c->stream, c->pair_stream})
+        if (st) HIPCHK(hipStreamSynchronize(st));
     return MAV_OK;
 }
 
@@ -331,29 +330,21 @@ extern "C" int mav_destroy(mav_ctx* c)
 {
     if (!c) return MAV_OK;
     hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
+    (void)sync_all_streams(c);
     for (auto& l : c->layers) free_layer(l);
-    if (c->prep_stream) hipStreamSynchronize(c->prep_stream);
-    if (c->pair_stream) hipStreamSynchronize(c->pair_stream);
-    for (auto& w : c->ws) {
-        void* wb[] = {w.I, w.R0, w.Ma, w.Mb, w.fc[0], w.fc[1], w.Htmp};      // R1 is the second half of R0's allocation
+    {
+        mav_ctx::WorkSet& w = c->ws;
+        void* wb[] = {w.I, w.R, w.Ma, w.Mb, w.fc[0], w.fc[1], w.Htmp};
         for (void* b : wb) if (b) hipFree(b);
     }
-    void* bufs[] = {c->flow_ws, c->foe_sc.cand, c->foe_sc.count,
-                    c->foe_sc.best_key, c->foe_dev, c->box_acc, c->u64_scratch, c->i32_scratch, c->derot_dev, c->pyr_ws, c->sat};
+    void* bufs[] = {c->flow_ws, c->foe_sc.cand, c->foe_sc.count, c->foe_sc.best_key, c->foe_sc.done, c->foe_dev, c->box_acc, c->u64_scratch,
+                    c->i32_scratch, c->derot_dev, c->pyr_ws, c->sat};
     for (void* b : bufs) if (b) hipFree(b);
     for (auto& blk : c->scratch) if (blk.p) hipFree(blk.p);
     for (auto& r : c->prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     if (c->prof_base) hipEventDestroy(c->prof_base);
-    if (c->t0) hipEventDestroy(c->t0);
-    if (c->t1) hipEventDestroy(c->t1);
-    if (c->copy_done) hipEventDestroy(c->copy_done);
-    if (c->compute_mark) hipEventDestroy(c->compute_mark);
-    for (hipEvent_t e : {c->prep_done[0], c->prep_done[1], c->fine_done[0], c->fine_done[1], c->call_begin, c->pif_fork, c->pif_join}) if (e) hipEventDestroy(e);
-    if (c->pair_stream) hipStreamDestroy(c->pair_stream);
-    if (c->prep_stream) hipStreamDestroy(c->prep_stream);
-    if (c->copy_stream) hipStreamDestroy(c->copy_stream);
-    if (c->stream) hipStreamDestroy(c->stream);
+    for (hipEvent_t e : {c->t0, c->t1, c->copy_done, c->compute_mark, c->pif_fork, c->pif_join}) if (e) hipEventDestroy(e);
+    for (hipStream_t st : {c->pair_stream, c->copy_stream, c->stream}) if (st) hipStreamDestroy(st);
     delete c;
     return MAV_OK;
 }
@@ -388,14 +379,9 @@ extern "C" int mav_create(mav_ctx** out, int device, int W, int H, int max_batch
     int rc = MAV_OK;
     auto bail = [&](int code) { mav_destroy(c); return code; };
 #define HIPB(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fail(e_ == hipErrorOutOfMemory ? MAV_ERR_OOM : MAV_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); return bail(e_ == hipErrorOutOfMemory ? MAV_ERR_OOM : MAV_ERR_HIP); } } while (0)
-    HIPB(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIPB(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-    HIPB(hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming));
-    HIPB(hipEventCreateWithFlags(&c->compute_mark, hipEventDisableTiming));
-    HIPB(hipStreamCreateWithFlags(&c->prep_stream, hipStreamNonBlocking));
-    for (hipEvent_t* e : {&c->prep_done[0], &c->prep_done[1], &c->fine_done[0], &c->fine_done[1], &c->call_begin, &c->pif_fork, &c->pif_join})
+    for (hipStream_t* st : {&c->stream, &c->copy_stream, &c->pair_stream}) HIPB(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+    for (hipEvent_t* e : {&c->copy_done, &c->compute_mark, &c->pif_fork, &c->pif_join})
         HIPB(hipEventCreateWithFlags(e, hipEventDisableTiming));
-    HIPB(hipStreamCreateWithFlags(&c->pair_stream, hipStreamNonBlocking));
     HIPB(hipEventCreate(&c->t0));
     HIPB(hipEventCreate(&c->t1));
     if (!prepare_poly(fb.poly_n, fb.poly_sigma, &c->pc)) { fail(MAV_ERR_ARG, "poly_sigma %g gives a singular moment matrix", fb.poly_sigma); return bail(MAV_ERR_ARG); }
@@ -428,28 +414,18 @@ extern "C" int mav_create(mav_ctx** out, int device, int W, int H, int max_batch
     c->n0 = (size_t)W * H;
     c->n1 = levels >= 1 ? (size_t)c->layers[1].w * c->layers[1].h : 0;
     c->htmp_stride = (size_t)H * W;                    // any layer (even layer 0 when its fast form does not apply) fits
-    // group: pairs per launch for everything but the finest layer's sweeps (see farneback_group).
+    // group: pairs per launch for everything but the finest layer's sweeps (see flow_group).
     // (1080p, 64 pairs: 27.0 - 27.5 ms with groups of 16 or 32, 27.8 - 28.1 with 8, 28.4 with 4 -- the batched blur / expansion
     // launches of 16 pairs run 10 - 15 % faster than two of 8; at 3840x2160 8 and 16 are equal, 4 is slower: profiles/r02/ab_group*.log)
     int group = (size_t)W * H <= ((size_t)4 << 20) ? 16 : 8;
     if (group > max_batch) group = max_batch;
-    if (const char* e = getenv("MAVFLOW_GROUP")) { int v = atoi(e); if (v >= 1) group = v < max_batch ? v : max_batch; }
-    if (const char* e = getenv("MAVFLOW_RC")) c->use_rc = atoi(e) != 0;
-    if (const char* e = getenv("MAVFLOW_GROUP_FINE")) { int v = atoi(e); if (v >= 0) c->group_fine = v; }
-    if (const char* e = getenv("MAVFLOW_PIPELINE")) c->pipeline = atoi(e) != 0;
-    if (const char* e = getenv("MAVFLOW_BANDS")) { int v = atoi(e); if (v >= 1 && v <= 8) { c->bands = v; c->bands_set = true; } }
-    if (const char* e = getenv("MAVFLOW_PAIRS_IN_FLIGHT")) { int v = atoi(e); if (v == 1 || v == 2) c->pairs_in_flight = v; }
-    if (const char* e = getenv("MAVFLOW_PIF_BAND_MB")) { int v = atoi(e); if (v >= 8) c->pif_band_mb = v; }
-    if (const char* e = getenv("MAVFLOW_COARSE_MB")) { int v = atoi(e); if (v >= 0) c->coarse_cache_mb = v; }
-    // One pair's finest-layer working set (80 B/px) fits the 256 MB Infinity Cache up to ~2.6 Mpx.  Beyond that the pair is swept
-    // band by band (sweeps_band_major), bands of at most ~230 MB (measured at 3840x2160, 16 pairs: 3 bands 31.6 ms, 4 bands 32.4,
-    // 5 bands 34.3, 6 bands 35.0, batched sweep-major 35.4); MAVFLOW_BANDS=1 with MAVFLOW_GROUP_FINE=0 gives the batched form.
-    if ((size_t)W * H * 80 > (size_t)200 << 20 && !getenv("MAVFLOW_GROUP_FINE")) {
-        c->group_fine = 1;
-        if (!getenv("MAVFLOW_BANDS")) {
-            c->bands = (int)(((size_t)W * H * 80 + ((size_t)230 << 20) - 1) / ((size_t)230 << 20));
-            if (c->bands > 8) c->bands = 8;
-        }
+    // One pair's finest-layer working set (80 B/px) fits the 256 MB Infinity Cache up to ~2.6 Mpx.  Beyond that a pair is swept
+    // band by band (sweeps_band_major): the one-stream schedule ("pairs_in_flight" = 1) over bands of at most ~230 MB (measured at
+    // 3840x2160, 16 pairs: 3 bands 31.6 ms, 4 bands 32.4, 5 bands 34.3, 6 bands 35.0, batched sweep-major 35.4); the default
+    // two-stream schedule sizes its own bands ("band_mb").
+    if ((size_t)W * H * 80 > (size_t)200 << 20) {
+        c->bands = (int)(((size_t)W * H * 80 + ((size_t)230 << 20) - 1) / ((size_t)230 << 20));
+        if (c->bands > 8) c->bands = 8;
     }
     rc = alloc_group(c, group);
     if (rc != MAV_OK) return bail(rc);
@@ -461,53 +437,65 @@ extern "C" int mav_create(mav_ctx** out, int device, int W, int H, int max_batch
     HIPB(hipMalloc(&c->derot_dev, sizeof(DerotParams) * B));
     HIPB(hipMalloc(&c->foe_sc.count, sizeof(int) * B));
     HIPB(hipMalloc(&c->foe_sc.best_key, sizeof(unsigned long long) * B));
+    HIPB(hipMalloc(&c->foe_sc.done, sizeof(unsigned) * 2 * B));
+    HIPB(hipMemset(c->foe_sc.done, 0, sizeof(unsigned) * 2 * B));
 #undef HIPB
     *out = c;
     return MAV_OK;
 }
 
+// ---- options: every scheduling / tuning switch of the library lives here (no environment variables) -----------------------------
+struct OptionDesc { const char* name; long lo, hi; };
+static const OptionDesc kOptions[] = {
+    {"group", 1, 1 << 20}, {"group_fine", 0, 1 << 20}, {"bands", 1, 8}, {"pairs_in_flight", 1, 2}, {"band_mb", 8, 1 << 20},
+    {"coarse_cache_mb", 0, 1 << 20}, {"coarse_half", 0, 1 << 20}, {"share_m", 0, 1}, {"share_frames", 0, 1}, {"strip", 0, 1 << 20},
+    {"phi_screen", 0, 1}, {"phi_yloop", 0, 1 << 20},
+};
+static long* option_slot(mav_ctx* c, const char* name, long* tmp)
+{
+    // int / bool members behind one long-typed view: *tmp carries the value, write_back stores it
+    struct { const char* n; long v; } cur[] = {
+        {"group", c->group}, {"group_fine", c->group_fine}, {"bands", c->bands}, {"pairs_in_flight", c->pairs_in_flight},
+        {"band_mb", c->pif_band_mb}, {"coarse_cache_mb", c->coarse_cache_mb}, {"coarse_half", c->coarse_half}, {"share_m", c->share_m},
+        {"share_frames", c->share_frames}, {"strip", c->strip}, {"phi_screen", c->phi_screen}, {"phi_yloop", c->phi_yloop},
+    };
+    for (auto& e : cur) if (!strcmp(e.n, name)) { *tmp = e.v; return tmp; }
+    return nullptr;
+}
+extern "C" int mav_get_option(mav_ctx* c, const char* name, long* value)
+{
+    if (!c || !name || !value) return fail(MAV_ERR_ARG, "mav_get_option: NULL argument");
+    long tmp;
+    if (!option_slot(c, name, &tmp)) return fail(MAV_ERR_ARG, "unknown option '%s'", name);
+    *value = tmp;
+    return MAV_OK;
+}
 extern "C" int mav_set_option(mav_ctx* c, const char* name, long value)
 {
     if (!c || !name) return fail(MAV_ERR_ARG, "mav_set_option: NULL argument");
+    const OptionDesc* d = nullptr;
+    for (const auto& o : kOptions) if (!strcmp(o.name, name)) d = &o;
+    if (!d) return fail(MAV_ERR_ARG, "unknown option '%s'", name);
+    if (value < d->lo || value > d->hi) return fail(MAV_ERR_ARG, "option '%s' must be in [%ld, %ld], got %ld", name, d->lo, d->hi, value);
+    const int v = (int)value;
     if (!strcmp(name, "group")) {
-        if (value < 1) return fail(MAV_ERR_ARG, "group must be >= 1");
-        int g = value > c->max_batch ? c->max_batch : (int)value;
+        const int g = v > c->max_batch ? c->max_batch : v;
         HIPCHK(hipSetDevice(c->device));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        HIPCHK(hipStreamSynchronize(c->prep_stream));
-        HIPCHK(hipStreamSynchronize(c->pair_stream));
+        CHK(sync_all_streams(c));
         return g == c->group ? MAV_OK : alloc_group(c, g);
     }
-    if (!strcmp(name, "bands")) {
-        if (value < 1 || value > 8) return fail(MAV_ERR_ARG, "bands must be in [1, 8]");
-        c->bands = (int)value;
-        c->bands_set = true;
-        return MAV_OK;
-    }
-    if (!strcmp(name, "pairs_in_flight")) {
-        if (value != 1 && value != 2) return fail(MAV_ERR_ARG, "pairs_in_flight must be 1 or 2");
-        c->pairs_in_flight = (int)value;
-        return MAV_OK;
-    }
-    if (!strcmp(name, "pipeline")) {      // the second work set exists only while the option is on
-        const bool on = value != 0;
-        if (on == c->pipeline) return MAV_OK;
-        HIPCHK(hipSetDevice(c->device));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        HIPCHK(hipStreamSynchronize(c->prep_stream));
-        c->pipeline = on;
-        const int rc = alloc_group(c, c->group);
-        if (rc != MAV_OK) c->pipeline = !on;
-        return rc;
-    }
-    if (!strcmp(name, "recompute")) { c->use_rc = value != 0; return MAV_OK; }
-    if (!strcmp(name, "share_frames")) { c->share_frames = value != 0; return MAV_OK; }
-    if (!strcmp(name, "group_fine")) {
-        if (value < 0) return fail(MAV_ERR_ARG, "group_fine must be >= 0 (0 = same as group)");
-        c->group_fine = (int)value;
-        return MAV_OK;
-    }
-    return fail(MAV_ERR_ARG, "unknown option '%s'", name);
+    if (!strcmp(name, "group_fine")) { c->group_fine = v; c->group_fine_set = true; }
+    else if (!strcmp(name, "bands")) { c->bands = v; c->bands_set = true; }
+    else if (!strcmp(name, "pairs_in_flight")) c->pairs_in_flight = v;
+    else if (!strcmp(name, "band_mb")) c->pif_band_mb = v;
+    else if (!strcmp(name, "coarse_cache_mb")) c->coarse_cache_mb = v;
+    else if (!strcmp(name, "coarse_half")) c->coarse_half = v;
+    else if (!strcmp(name, "share_m")) c->share_m = v != 0;
+    else if (!strcmp(name, "share_frames")) c->share_frames = v != 0;
+    else if (!strcmp(name, "strip")) c->strip = v;
+    else if (!strcmp(name, "phi_screen")) c->phi_screen = v != 0;
+    else if (!strcmp(name, "phi_yloop")) c->phi_yloop = v;
+    return MAV_OK;
 }
 
 extern "C" int mav_num_layers(const mav_ctx* c) { return c ? (int)c->layers.size() : 0; }
@@ -605,8 +593,7 @@ static int prof_collect(mav_ctx* c)
 {
     while (!c->open_runs.empty()) close_run(c, c->open_runs.size() - 1);
     if (c->prof.empty()) return MAV_OK;
-    HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipStreamSynchronize(c->pair_stream));
+    CHK(sync_all_streams(c));
     for (auto& r : c->prof) {
         float ms = 0, t0 = 0;
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
@@ -681,10 +668,71 @@ static int check_launch(const char* what)
     return MAV_OK;
 }
 
-// ---- Farneback pipeline ----------------------------------------------------------------------------------
+// ---- Farneback: the schedule of one group of pairs --------------------------------------------------------------------
 static BlurParams blur_of(const mav_ctx* c, const Layer& l)
 {
     return BlurParams{l.ksize, (l.ksize == 3 && l.sigma <= 0) ? 1 : 0, l.g, (double)c->W / l.w, (double)c->H / l.h};
+}
+
+// How the sweeps of layer k run for a group of g pairs (plan_sweeps decides, layer_sweeps executes, mav_schedule_info reports).
+enum { SW_SEQ = 0, SW_TWO_PAIRS = 1, SW_COARSE_TWO = 2 };
+struct SweepPlan {
+    int mode;        // SW_SEQ: sub-groups one after the other on one stream; SW_TWO_PAIRS: finest layer, pairs alternate between two
+                     // streams, each band-major; SW_COARSE_TWO: coarse layer, sub-groups of `half` pairs alternate between two streams
+    int sub;         // pairs per launch (SW_SEQ)
+    int J;           // horizontal bands per pair (finest layer, one pair per launch); 1 = sweep-major
+    int half;        // SW_COARSE_TWO: pairs per launch
+    bool m_per_sub;  // the initial M of a sub-group is built right before its sweeps
+};
+static SweepPlan plan_sweeps(const mav_ctx* c, int k, int g, bool bands_ok)
+{
+    const Layer& l = c->layers[k];
+    const int T = blur_iter_tile_rows(l.h), I = c->fb.iterations;
+    SweepPlan p{SW_SEQ, g, 1, 0, false};
+    // The finest layer's ten sweeps re-read R0/R1 and M: run them `group_fine` pairs at a time so that one sub-group's working
+    // set stays resident in the 256 MB Infinity Cache between sweeps.  Coarse layers are small: as many pairs per launch as keep
+    // the sweeps' working set cache-sized, to fill the 256 CUs.
+    if (k == 0 && c->group_fine > 0 && c->group_fine < g) p.sub = c->group_fine;
+    if (k > 0 && c->coarse_cache_mb > 0) {
+        const size_t ws = (size_t)l.w * l.h * 80, cap = (size_t)c->coarse_cache_mb << 20;
+        const int fit = (int)(cap / (ws ? ws : 1));
+        if (fit < p.sub) p.sub = fit > 1 ? fit : 1;
+    }
+    // with per-sub-group sweeps the initial M of a sub-group is built right before its sweeps: M, R0 and R1 are then still in the
+    // Infinity Cache when the first sweep reads them (measured -0.5 ms per 64 pairs; doing the same with the blur and the expansion
+    // costs more in small launches than it returns)
+    p.m_per_sub = p.sub < g;
+    if (k > 0 && c->pairs_in_flight == 2 && g >= 2) {
+        // COARSE LAYERS with two sub-groups in flight: sub-groups of half the cache-sized count alternate between the compute stream
+        // and pair_stream, each with its own M slots, for the same reason as the pairs of the finest layer below -- 25.5 - 25.6 vs
+        // 26.0 - 26.6 ms per 64 pairs at 1080p with 4 + 4 instead of 8 pairs per launch (3 + 3: 25.7 - 25.8; 8 + 8: 26.4;
+        // profiles/r02/ab_coarse_two*.log).
+        p.mode = SW_COARSE_TWO;
+        p.half = p.sub / 2 > 0 ? p.sub / 2 : 1;
+        if (c->coarse_half > 0) p.half = c->coarse_half;
+        if (2 * p.half > g) p.half = (g + 1) / 2;
+        return p;
+    }
+    if (k == 0 && c->pairs_in_flight == 2 && p.m_per_sub && p.sub == 1 && g >= 2) {
+        // TWO PAIRS IN FLIGHT (finest layer, one pair per launch).  Pair s of the group runs on stream s & 1 -- the compute stream
+        // and pair_stream -- and ping-pongs M through slot s & 1.  The two streams never wait for each other inside the group
+        // (different pairs: no dependency; one fork and one join event per group), so one stream's launches fill the kernel
+        // boundaries and the fill / drain of the other's.  What keeps this inside the 256 MB Infinity Cache is the band-major order:
+        // each pair is swept (and its initial M built) band by band, bands of at most 86 MB of working set -- 2 bands at 1080p, 8 at
+        // 3840x2160 -- so the hot set is 2 x 83 MB, what ONE whole 1080p pair occupies in the one-stream schedule.  Measured
+        // (profiles/r02/ab_two_pairs*.log): 1080p 25.9 - 26.3 vs 27.1 - 27.4 ms per 64 pairs, 4K 28.7 vs 30.1 ms per 16 pairs; two full
+        // pairs without bands 28.6 ms, three or four streams 27.9 - 28.1 ms.  Same tiles, same arithmetic as every other schedule:
+        // bit-identical flow (tests/test_gpu_flow.py).
+        const size_t ws = (size_t)l.w * l.h * 80, band = (size_t)c->pif_band_mb << 20;
+        int J = c->bands_set ? c->bands : (int)((ws + band - 1) / band);
+        const int Jmax = T / (I + 2);          // a band needs iterations + 2 tile rows (the skew must not reach the image top)
+        if (J > Jmax) J = Jmax;
+        if (J < 1) J = 1;
+        if (J == 1 || bands_ok) { p.mode = SW_TWO_PAIRS; p.J = J; return p; }
+    }
+    // one stream; bands (finest layer, one pair per launch): at least iterations + 2 tile rows each
+    if (k == 0 && (p.m_per_sub || g == 1) && p.sub == 1 && T >= (I + 2) * c->bands && bands_ok) p.J = c->bands;
+    return p;
 }
 
 // The finest layer's sweeps of one pair in BAND-MAJOR order, for frames whose per-pair working set (80 B per pixel: M in, M out,
@@ -699,9 +747,6 @@ static BlurParams blur_of(const mav_ctx* c, const Layer& l)
 //     been overwritten by (it + 1, j - 1) only up to one tile row above them.  A skew of one tile row (16 >= 6 pixels) covers both.
 // Every tile is computed exactly once on the same tile grid: results are bit-identical to the sweep-major schedule
 // (tests/test_gpu_flow.py).  One stream, no events.
-// (A two-stream variant of the same skew -- consecutive sweeps of one 1080p pair in flight together on different bands, to break
-// the lockstep of a per-pair launch -- was built, parity-green, and dropped: every cross-stream event wait costs ~6 us, 36.6 vs
-// 28.8 ms per 64 pairs.)
 // upd != nullptr: the initial M (UpdateMatrices from the coarser layer's flow) is built band by band too, right before a band's
 // first sweep: pixel rows [16 a0 - 8, 16 a1 + 8) -- what that sweep reads (6-pixel halo) -- which lie below everything the bands
 // above have written into Ma (their odd sweeps end one whole tile row higher); the rows two neighbouring bands both need are
@@ -720,232 +765,170 @@ static void sweeps_band_major(mav_ctx* c, hipStream_t st, int kid, float* Ma, fl
                                    j == 0 ? 0 : a0 * 16 - 8, j == J - 1 ? lh : a1 * 16 + 8);
         }
         for (int it = 0; it < I; it++) {
-            const int upd = it < I - 1;
+            const int update = it < I - 1;
             int ty0 = j == 0 ? 0 : a0 - it, ty1 = j == J - 1 ? T : a1 - it;
             if (ty0 < 0) ty0 = 0;
             if (ty1 <= ty0) continue;
             ProfScope ps(c, kid, st);
-            launch_blur_iter(st, (it & 1) ? Mb : Ma, (it & 1) ? Ma : Mb, 5 * n0, r0, r1, 5 * n0, gs, lw, lh, c->fb.winsize, upd, !upd, fo,
-                             fstride, ty0, ty1);
+            launch_blur_iter(st, (it & 1) ? Mb : Ma, (it & 1) ? Ma : Mb, 5 * n0, r0, r1, 5 * n0, gs, lw, lh, c->fb.winsize, update, !update, fo,
+                             fstride, ty0, ty1, c->strip);
         }
     }
 }
 
-// Initial M and the `iterations` sweeps of layer k for g slots of work set w, on stream st.  flow_prev = the coarser layer's
-// flow (pw x ph, nullptr at the top layer); the layer's flow goes to fdst (slot stride fstride).
-static void layer_sweeps(mav_ctx* c, mav_ctx::WorkSet& w, hipStream_t st, int k, int g, const float* flow_prev, size_t fc_stride, int pw,
-                         int ph, float* fdst, size_t fstride)
+// initial M + the `iterations` sweeps of gs pairs, sweep-major, on stream ss
+static void sweeps_plain(mav_ctx* c, hipStream_t ss, int kid, float* Min, float* Mout, const float* r0, const float* r1, int gs, const Layer& l,
+                         float* fo, size_t fstride)
 {
+    const size_t n0 = c->n0;
+    for (int it = 0; it < c->fb.iterations; it++) {
+        const int update = it < c->fb.iterations - 1;
+        { ProfScope ps(c, kid, ss);
+          launch_blur_iter(ss, Min, Mout, 5 * n0, r0, r1, 5 * n0, gs, l.w, l.h, c->fb.winsize, update, !update, fo, fstride, 0, -1, c->strip); }
+        if (update) { float* t = Min; Min = Mout; Mout = t; }
+    }
+}
+
+// Initial M and the `iterations` sweeps of layer k for g pairs whose expansions lie at r0 / r1 (slot stride 5 n0), starting on
+// stream st.  flow_prev = the coarser layer's flow (pw x ph, nullptr at the top layer); the layer's flow goes to fdst (slot stride
+// fstride).  On return everything has been joined back into st.
+static int layer_sweeps(mav_ctx* c, hipStream_t st, int k, int g, const float* r0g, const float* r1g, const float* flow_prev, size_t fc_stride,
+                        int pw, int ph, float* fdst, size_t fstride)
+{
+    mav_ctx::WorkSet& w = c->ws;
     const size_t n0 = c->n0;
     const Layer& l = c->layers[k];
     const float mul = (float)(1. / c->fb.pyr_scale);
-    // The finest layer's ten sweeps re-read R0/R1 (and M or the flow): run them `group_fine` pairs at a time so that
-    // one sub-group's working set stays resident in the 256 MB Infinity Cache between sweeps.  Coarse layers are
-    // small: all g pairs per launch to fill the 256 CUs.
-    int sub = (k == 0 && c->group_fine > 0 && c->group_fine < g) ? c->group_fine : g;
-    if (k > 0 && c->coarse_cache_mb > 0) {        // coarse layers: as many pairs per launch as keep the sweeps' working set cache-sized
-        const size_t ws = (size_t)l.w * l.h * 80, cap = (size_t)c->coarse_cache_mb << 20;
-        const int fit = (int)(cap / (ws ? ws : 1));
-        if (fit < sub) sub = fit > 1 ? fit : 1;
-    }
-    // Optional form ("recompute"): sweeps that rebuild M from (R0, R1, flow) on the fly -- no M arrays, no initial-M
-    // kernel, 56 instead of 80 B/px of HBM traffic; the flow ping-pongs between the (otherwise unused) Ma / Mb buffers.
-    // On MI355X at 1080p it is slower than the M-array form (27.6 vs 21.3 ms per 64 pairs: the limit is the per-CU
-    // request rate into L2, which the 2.08x halo recomputation raises), so it is off by default.
-    bool rc_ok = c->use_rc && c->fb.winsize / 2 == 6 && l.w % 4 == 0;
-    if (rc_ok) {
-        for (int s0 = 0; s0 < g && rc_ok; s0 += sub) {
-            const int gs = g - s0 < sub ? g - s0 : sub;
-            float* buf[2] = {w.Ma + (size_t)s0 * 5 * n0, w.Mb + (size_t)s0 * 5 * n0};
-            for (int it = 0; it < c->fb.iterations; it++) {
-                const bool last = it == c->fb.iterations - 1;
-                const int mode = it > 0 ? 2 : (flow_prev ? 1 : 0);
-                const float* fin = it > 0 ? buf[(it - 1) & 1] : (flow_prev ? flow_prev + (size_t)s0 * fc_stride : nullptr);
-                const size_t fin_stride = it > 0 ? 5 * n0 : fc_stride;
-                float* fo = last ? fdst + (size_t)s0 * fstride : buf[it & 1];
-                ProfScope ps(c, k == 0 ? K_ITER : K_ITER_COARSE, st);
-                if (!launch_sweep_rc(st, mode, fin, fin_stride, pw, ph, mul, w.r0 + (size_t)s0 * 5 * n0,
-                                     w.r1 + (size_t)s0 * 5 * n0, 5 * n0, gs, l.w, l.h, c->fb.winsize, fo, last ? fstride : 5 * n0)) {
-                    rc_ok = false;      // (only possible on the very first launch: alignment) -> M-array form below
-                    break;
-                }
+    const bool bands_ok = blur_iter_bands_ok(l.w, c->fb.winsize, 5 * n0, 5 * n0, fstride, w.Ma, w.Mb, r0g, r1g, fdst);
+    const SweepPlan p = plan_sweeps(c, k, g, bands_ok);
+    const int kid = k == 0 ? K_ITER : K_ITER_COARSE;
+    const int T = blur_iter_tile_rows(l.h);
+    if (p.mode == SW_TWO_PAIRS) {
+        HIPCHK(hipEventRecord(c->pif_fork, st));
+        HIPCHK(hipStreamWaitEvent(c->pair_stream, c->pif_fork, 0));
+        for (int s0 = 0; s0 < g; s0++) {
+            const hipStream_t ss = (s0 & 1) ? c->pair_stream : st;
+            float *Min = w.Ma + (size_t)(s0 & 1) * 5 * n0, *Mout = w.Mb + (size_t)(s0 & 1) * 5 * n0;
+            const float *r0 = r0g + (size_t)s0 * 5 * n0, *r1 = r1g + (size_t)s0 * 5 * n0;
+            float* fo = fdst + (size_t)s0 * fstride;
+            const BandUpdate bu{flow_prev ? flow_prev + (size_t)s0 * fc_stride : nullptr, fc_stride, pw, ph, mul};
+            if (p.J > 1) {
+                sweeps_band_major(c, ss, K_ITER, Min, Mout, r0, r1, 1, l.w, l.h, T, p.J, fo, fstride, &bu);
+                continue;
             }
-        }
-    }
-    if (rc_ok) return;
-    // with per-sub-group sweeps the initial M of a sub-group is built right before its sweeps: M, R0 and R1 are then
-    // still in the Infinity Cache when the first sweep reads them (measured -0.5 ms per 64 pairs; doing the same with the
-    // blur and the expansion costs more in small launches than it returns)
-    const bool m_per_sub = sub < g;
-    const bool coarse_two = k > 0 && c->pairs_in_flight == 2 && g >= 2 && st == c->stream && !c->pipeline;     // see below
-    if (!m_per_sub && !coarse_two) {
-        ProfScope ps(c, K_UPDATE, st);
-        launch_update_matrices(st, w.r0, w.r1, 5 * n0, flow_prev, fc_stride, pw, ph, mul, g, l.w, l.h, w.Ma, 5 * n0);
-    }
-    // Sub-groups are swept one after the other on one stream, so they all ping-pong M through the SAME two buffers (the first
-    // sub-group's slots): the M lines then stay hot in the Infinity Cache from pair to pair instead of leaving a dead 83 MB copy
-    // behind per pair.  Measured at 1080p, 64 pairs: 27.6 / 28.0 ms shared vs 28.2 / 28.6 ms with per-slot buffers (same box,
-    // alternating); MAVFLOW_SHARE_M=0 restores per-slot buffers.  (Going further -- building each pair's images and expansions
-    // right before its sweeps into one shared I / R0 / R1 as well, so that all 166 MB stay resident -- costs more in single-image
-    // blur / expansion launches, 3.0 + 1.7 vs 2.0 + 0.9 ms, than the warmer initial M and first sweep return: 28.4 vs 27.4 ms.)
-    static int share_m = -1;
-    if (share_m < 0) { const char* e = getenv("MAVFLOW_SHARE_M"); share_m = e ? atoi(e) : 1; }
-    // TWO PAIRS IN FLIGHT (default; finest layer, one pair per launch).  Pair s0 of the group runs on stream s0 & 1 -- the compute
-    // stream and pair_stream -- and ping-pongs M through slot s0 & 1.  The two streams never wait for each other inside the group
-    // (different pairs: no dependency; one fork and one join event per group), so one stream's launches fill the kernel
-    // boundaries and the fill / drain of the other's.  What keeps this inside the 256 MB Infinity Cache is the band-major order:
-    // each pair is swept (and its initial M built) band by band, bands of at most 86 MB of working set -- 2 bands at 1080p, 8 at
-    // 3840x2160 -- so the hot set is 2 x 83 MB, what ONE whole 1080p pair occupies in the one-stream schedule.  Measured
-    // (profiles/r02/ab_two_pairs*.log): 1080p 25.9 - 26.3 vs 27.1 - 27.4 ms per 64 pairs, 4K 28.7 vs 30.1 ms per 16 pairs; two full
-    // pairs without bands 28.6 ms, three or four streams 27.9 - 28.1 ms.  Same tiles, same arithmetic as every other schedule:
-    // bit-identical flow (tests/test_gpu_flow.py).
-    if (k == 0 && c->pairs_in_flight == 2 && m_per_sub && sub == 1 && g >= 2 && st == c->stream && !c->pipeline) {
-        const int T = blur_iter_tile_rows(l.h);
-        const size_t ws = (size_t)l.w * l.h * 80, band = (size_t)c->pif_band_mb << 20;
-        int J = c->bands_set ? c->bands : (int)((ws + band - 1) / band);
-        const int Jmax = T / (c->fb.iterations + 2);          // a band needs iterations + 2 tile rows (the skew must not reach the image top)
-        if (J > Jmax) J = Jmax;
-        if (J < 1) J = 1;
-        if (J == 1 || blur_iter_bands_ok(l.w, c->fb.winsize, 5 * n0, 5 * n0, fstride, w.Ma, w.Mb, w.r0, w.r1, fdst)) {
-            hipEventRecord(c->pif_fork, st);
-            hipStreamWaitEvent(c->pair_stream, c->pif_fork, 0);
-            for (int s0 = 0; s0 < g; s0++) {
-                const hipStream_t ss = (s0 & 1) ? c->pair_stream : st;
-                float *Min = w.Ma + (size_t)(s0 & 1) * 5 * n0, *Mout = w.Mb + (size_t)(s0 & 1) * 5 * n0;
-                const float *r0 = w.r0 + (size_t)s0 * 5 * n0, *r1 = w.r1 + (size_t)s0 * 5 * n0;
-                float* fo = fdst + (size_t)s0 * fstride;
-                const BandUpdate bu{flow_prev ? flow_prev + (size_t)s0 * fc_stride : nullptr, fc_stride, pw, ph, mul};
-                if (J > 1) {
-                    sweeps_band_major(c, ss, K_ITER, Min, Mout, r0, r1, 1, l.w, l.h, T, J, fo, fstride, &bu);
-                    continue;
-                }
-                { ProfScope ps(c, K_UPDATE, ss);
-                  launch_update_matrices(ss, r0, r1, 5 * n0, bu.flow_prev, fc_stride, pw, ph, mul, 1, l.w, l.h, Min, 5 * n0); }
-                for (int it = 0; it < c->fb.iterations; it++) {
-                    const int upd = it < c->fb.iterations - 1;
-                    { ProfScope ps(c, K_ITER, ss);
-                      launch_blur_iter(ss, Min, Mout, 5 * n0, r0, r1, 5 * n0, 1, l.w, l.h, c->fb.winsize, upd, !upd, fo, fstride); }
-                    if (upd) { float* t = Min; Min = Mout; Mout = t; }
-                }
-            }
-            prof_close_stream(c, c->pair_stream); prof_close_stream(c, st);
-            hipEventRecord(c->pif_join, c->pair_stream);
-            hipStreamWaitEvent(st, c->pif_join, 0);
-            return;
-        }
-    }
-    // COARSE LAYERS with two sub-groups in flight (option "pairs_in_flight" = 2): sub-groups of half the cache-sized count alternate
-    // between the compute stream and pair_stream, each with its own M slots, for the same reason as the pairs of the finest layer
-    // above -- 25.5 - 25.6 vs 26.0 - 26.6 ms per 64 pairs at 1080p with 4 + 4 instead of 8 pairs per launch (3 + 3: 25.7 - 25.8;
-    // 8 + 8: 26.4; profiles/r02/ab_coarse_two*.log).
-    if (coarse_two) {
-        int half = sub / 2 > 0 ? sub / 2 : 1;
-        static int coarse_half = -1;
-        if (coarse_half < 0) { const char* e = getenv("MAVFLOW_COARSE_HALF"); coarse_half = e ? atoi(e) : 0; }
-        if (coarse_half > 0) half = coarse_half;
-        if (2 * half > g) half = (g + 1) / 2;
-        hipEventRecord(c->pif_fork, st);
-        hipStreamWaitEvent(c->pair_stream, c->pif_fork, 0);
-        int idx = 0;
-        for (int s0 = 0; s0 < g; s0 += half, idx++) {
-            const int gs = g - s0 < half ? g - s0 : half;
-            const hipStream_t ss = (idx & 1) ? c->pair_stream : st;
-            const size_t m_off = (size_t)(idx & 1) * half * 5 * n0;
-            float *Min = w.Ma + m_off, *Mout = w.Mb + m_off;
-            const float *r0 = w.r0 + (size_t)s0 * 5 * n0, *r1 = w.r1 + (size_t)s0 * 5 * n0;
             { ProfScope ps(c, K_UPDATE, ss);
-              launch_update_matrices(ss, r0, r1, 5 * n0, flow_prev ? flow_prev + (size_t)s0 * fc_stride : nullptr, fc_stride, pw, ph, mul, gs, l.w, l.h,
-                                     Min, 5 * n0); }
-            for (int it = 0; it < c->fb.iterations; it++) {
-                const int upd = it < c->fb.iterations - 1;
-                { ProfScope ps(c, K_ITER_COARSE, ss);
-                  launch_blur_iter(ss, Min, Mout, 5 * n0, r0, r1, 5 * n0, gs, l.w, l.h, c->fb.winsize, upd, !upd, fdst + (size_t)s0 * fstride, fstride); }
-                if (upd) { float* t = Min; Min = Mout; Mout = t; }
-            }
+              launch_update_matrices(ss, r0, r1, 5 * n0, bu.flow_prev, fc_stride, pw, ph, mul, 1, l.w, l.h, Min, 5 * n0); }
+            sweeps_plain(c, ss, K_ITER, Min, Mout, r0, r1, 1, l, fo, fstride);
         }
         prof_close_stream(c, c->pair_stream); prof_close_stream(c, st);
-        hipEventRecord(c->pif_join, c->pair_stream);
-        hipStreamWaitEvent(st, c->pif_join, 0);
-        return;
+        HIPCHK(hipEventRecord(c->pif_join, c->pair_stream));
+        HIPCHK(hipStreamWaitEvent(st, c->pif_join, 0));
+        return MAV_OK;
     }
-    for (int s0 = 0; s0 < g; s0 += sub) {
-        const int gs = g - s0 < sub ? g - s0 : sub;
-        const size_t m_off = (m_per_sub && share_m) ? 0 : (size_t)s0 * 5 * n0;
-        if (m_per_sub) {
+    if (p.mode == SW_COARSE_TWO) {
+        HIPCHK(hipEventRecord(c->pif_fork, st));
+        HIPCHK(hipStreamWaitEvent(c->pair_stream, c->pif_fork, 0));
+        int idx = 0;
+        for (int s0 = 0; s0 < g; s0 += p.half, idx++) {
+            const int gs = g - s0 < p.half ? g - s0 : p.half;
+            const hipStream_t ss = (idx & 1) ? c->pair_stream : st;
+            const size_t m_off = (size_t)(idx & 1) * p.half * 5 * n0;
+            const float *r0 = r0g + (size_t)s0 * 5 * n0, *r1 = r1g + (size_t)s0 * 5 * n0;
+            { ProfScope ps(c, K_UPDATE, ss);
+              launch_update_matrices(ss, r0, r1, 5 * n0, flow_prev ? flow_prev + (size_t)s0 * fc_stride : nullptr, fc_stride, pw, ph, mul, gs, l.w, l.h,
+                                     w.Ma + m_off, 5 * n0); }
+            sweeps_plain(c, ss, K_ITER_COARSE, w.Ma + m_off, w.Mb + m_off, r0, r1, gs, l, fdst + (size_t)s0 * fstride, fstride);
+        }
+        prof_close_stream(c, c->pair_stream); prof_close_stream(c, st);
+        HIPCHK(hipEventRecord(c->pif_join, c->pair_stream));
+        HIPCHK(hipStreamWaitEvent(st, c->pif_join, 0));
+        return MAV_OK;
+    }
+    if (!p.m_per_sub) {
+        ProfScope ps(c, K_UPDATE, st);
+        launch_update_matrices(st, r0g, r1g, 5 * n0, flow_prev, fc_stride, pw, ph, mul, g, l.w, l.h, w.Ma, 5 * n0);
+    }
+    // Sub-groups are swept one after the other on one stream, so they all ping-pong M through the SAME two buffers (the first
+    // sub-group's slots; option "share_m"): the M lines then stay hot in the Infinity Cache from pair to pair instead of leaving a
+    // dead 83 MB copy behind per pair.  Measured at 1080p, 64 pairs: 27.6 / 28.0 ms shared vs 28.2 / 28.6 ms with per-slot buffers.
+    for (int s0 = 0; s0 < g; s0 += p.sub) {
+        const int gs = g - s0 < p.sub ? g - s0 : p.sub;
+        const size_t m_off = (p.m_per_sub && c->share_m) ? 0 : (size_t)s0 * 5 * n0;
+        const float *r0 = r0g + (size_t)s0 * 5 * n0, *r1 = r1g + (size_t)s0 * 5 * n0;
+        if (p.m_per_sub) {
             ProfScope ps(c, K_UPDATE, st);
-            launch_update_matrices(st, w.r0 + (size_t)s0 * 5 * n0, w.r1 + (size_t)s0 * 5 * n0, 5 * n0,
-                                   flow_prev ? flow_prev + (size_t)s0 * fc_stride : nullptr, fc_stride, pw, ph, mul, gs, l.w, l.h,
-                                   w.Ma + m_off, 5 * n0);
+            launch_update_matrices(st, r0, r1, 5 * n0, flow_prev ? flow_prev + (size_t)s0 * fc_stride : nullptr, fc_stride, pw, ph, mul, gs, l.w,
+                                   l.h, w.Ma + m_off, 5 * n0);
         }
-        float *Min = w.Ma + m_off, *Mout = w.Mb + m_off;
-        const float *r0 = w.r0 + (size_t)s0 * 5 * n0, *r1 = w.r1 + (size_t)s0 * 5 * n0;
         float* fo = fdst + (size_t)s0 * fstride;
-        const int T = blur_iter_tile_rows(l.h);
-        // bands (finest layer, one pair per launch): at least iterations + 2 tile rows each, so that the skewed band edges never
-        // reach the top of the image
-        const int J = (k == 0 && (m_per_sub || g == 1) && gs == 1 && T >= (c->fb.iterations + 2) * c->bands &&
-                       blur_iter_bands_ok(l.w, c->fb.winsize, 5 * n0, 5 * n0, fstride, Min, Mout, r0, r1, fo)) ? c->bands : 1;
-        if (J > 1) {
-            sweeps_band_major(c, st, K_ITER, Min, Mout, r0, r1, gs, l.w, l.h, T, J, fo, fstride);
-            continue;
-        }
-        for (int it = 0; it < c->fb.iterations; it++) {
-            const int upd = it < c->fb.iterations - 1;
-            { ProfScope ps(c, k == 0 ? K_ITER : K_ITER_COARSE, st);
-              launch_blur_iter(st, Min, Mout, 5 * n0, r0, r1, 5 * n0, gs,
-                               l.w, l.h, c->fb.winsize, upd, !upd, fo, fstride); }
-            if (upd) { float* t = Min; Min = Mout; Mout = t; }
-        }
+        if (p.J > 1 && gs == 1) sweeps_band_major(c, st, K_ITER, w.Ma + m_off, w.Mb + m_off, r0, r1, gs, l.w, l.h, T, p.J, fo, fstride);
+        else sweeps_plain(c, st, kid, w.Ma + m_off, w.Mb + m_off, r0, r1, gs, l, fo, fstride);
     }
+    return MAV_OK;
 }
 
-// Layer images and polynomial expansions of both frames at layer k (g slots of set w, stream st) -> w.r0, w.r1.
+// Layer images and polynomial expansions of both frames of g pairs at layer k, on stream st, through image buffer I into the
+// expansion set R (R0 | R1 in one piece); *r0 / *r1 = where pair 0's two expansions lie (pair s: + s * 5 n0).
 // seq: `prev` is a run of g + 1 consecutive frames and pair s = (frame s, frame s + 1): every frame is blurred and expanded ONCE.
-static void layer_expansions(mav_ctx* c, mav_ctx::WorkSet& w, hipStream_t st, int k, const uint8_t* prev, const uint8_t* next, int g, bool seq)
+// Otherwise, when the 2 g layer images are small (merge_frames), prev and next go through ONE blur and ONE expansion launch of 2 g
+// images instead of two of g: a group of one or two pairs is bound by launch latency, not by bytes.
+static void layer_expansions(mav_ctx* c, hipStream_t st, int k, const uint8_t* prev, const uint8_t* next, int g, bool seq, float* I, float* R,
+                             const float** r0, const float** r1)
 {
+    mav_ctx::WorkSet& w = c->ws;
     const size_t n0 = c->n0;
     const Layer& l = c->layers[k];
     if (seq) {
         { ProfScope ps(c, K_BLUR_RESIZE, st);
-          launch_blur_resize(st, prev, n0, g + 1, c->W, c->H, l.w, l.h, blur_of(c, l), w.Htmp, c->htmp_stride, w.I, n0); }
+          launch_blur_resize(st, prev, nullptr, 0, n0, g + 1, c->W, c->H, l.w, l.h, blur_of(c, l), w.Htmp, c->htmp_stride, I, n0); }
         { ProfScope ps(c, K_POLYEXP, st);
-          launch_polyexp(st, w.I, n0, g + 1, l.w, l.h, c->pc, w.R0, 5 * n0); }
-        w.r0 = w.R0; w.r1 = w.R0 + 5 * n0;
+          launch_polyexp(st, I, n0, g + 1, l.w, l.h, c->pc, R, 5 * n0); }
+        *r0 = R; *r1 = R + 5 * n0;
+        return;
+    }
+    float* R1 = R + 5 * n0 * (size_t)g;
+    *r0 = R; *r1 = R1;
+    // (the two-pass blur's scratch holds g + 1 frames)
+    const bool no_tmp = !blur_resize_needs_tmp(prev, next, n0, c->W, c->H, l.w, l.h, blur_of(c, l), I, n0);
+    const bool merge_frames = (no_tmp || 2 * g <= g + 1) && (size_t)2 * g * l.w * l.h * sizeof(float) <= ((size_t)48 << 20);
+    if (merge_frames) {
+        { ProfScope ps(c, K_BLUR_RESIZE, st);
+          launch_blur_resize(st, prev, next, g, n0, 2 * g, c->W, c->H, l.w, l.h, blur_of(c, l), w.Htmp, c->htmp_stride, I, n0); }
+        { ProfScope ps(c, K_POLYEXP, st);
+          launch_polyexp(st, I, n0, 2 * g, l.w, l.h, c->pc, R, 5 * n0); }
         return;
     }
     const uint8_t* img[2] = {prev, next};
-    float* R[2] = {w.R0, w.R1};
+    float* Rs[2] = {R, R1};
     for (int i = 0; i < 2; i++) {
         { ProfScope ps(c, K_BLUR_RESIZE, st);
-          launch_blur_resize(st, img[i], n0, g, c->W, c->H, l.w, l.h, blur_of(c, l), w.Htmp, c->htmp_stride, w.I, n0); }
+          launch_blur_resize(st, img[i], nullptr, 0, n0, g, c->W, c->H, l.w, l.h, blur_of(c, l), w.Htmp, c->htmp_stride, I, n0); }
         { ProfScope ps(c, K_POLYEXP, st);
-          launch_polyexp(st, w.I, n0, g, l.w, l.h, c->pc, R[i], 5 * n0); }
+          launch_polyexp(st, I, n0, g, l.w, l.h, c->pc, Rs[i], 5 * n0); }
     }
-    w.r0 = w.R0; w.r1 = w.R1;
 }
 
-// PREPARATION of a group: every coarse layer completely (top layer first), then the finest layer's images and expansions.
-// Leaves in w: r0 / r1 of layer 0 and, when there is a coarse layer, layer 1's flow in w.fc[1].
-static void prep_group(mav_ctx* c, mav_ctx::WorkSet& w, hipStream_t st, const uint8_t* prev, const uint8_t* next, int g, bool seq)
+// One group of g pairs: every coarse layer completely (top layer first: images, expansions, initial M, sweeps), then the finest layer.
+// (Measured for groups of ONE pair, where the coarse layers are a chain of launches that each fill a fraction of the chip, and not
+// kept: the finest layer's images and expansions on a side stream underneath that chain.  Each of the two event operations the fork
+// and the join put on the compute stream costs ~6 us there, and the overlapped kernels slow the chain's own: 0.320 vs 0.306 ms per
+// 1280x720 pair, profiles/r03/c2_side_stream.txt.  For big groups the overlap loses too: the coarse layers' sweeps are cache-bound
+// and a concurrent HBM stream takes its share, profiles/r02/ab_overlap_fine_prep_with_coarse_sweeps.log.)
+static int flow_group(mav_ctx* c, const uint8_t* prev, const uint8_t* next, int g, bool seq, float* flow_out)
 {
+    mav_ctx::WorkSet& w = c->ws;
+    const hipStream_t st = c->stream;
     const int L = (int)c->layers.size();
     const size_t fc_stride = 2 * (c->n1 ? c->n1 : 1);
+    const float *r0 = nullptr, *r1 = nullptr;
     const float* flow_prev = nullptr;
     int pw = 0, ph = 0;
-    for (int k = L - 1; k >= 1; k--) {
-        layer_expansions(c, w, st, k, prev, next, g, seq);
-        layer_sweeps(c, w, st, k, g, flow_prev, fc_stride, pw, ph, w.fc[k & 1], fc_stride);
+    for (int k = L - 1; k >= 0; k--) {
+        layer_expansions(c, st, k, prev, next, g, seq, w.I, w.R, &r0, &r1);
+        CHK(layer_sweeps(c, st, k, g, r0, r1, flow_prev, fc_stride, pw, ph, k ? w.fc[k & 1] : flow_out, k ? fc_stride : 2 * c->n0));
         flow_prev = w.fc[k & 1]; pw = c->layers[k].w; ph = c->layers[k].h;
     }
-    layer_expansions(c, w, st, 0, prev, next, g, seq);
-}
-// SWEEPS of a group: the finest layer's initial M and iterations -> flow_out.
-static void fine_group(mav_ctx* c, mav_ctx::WorkSet& w, hipStream_t st, int g, float* flow_out)
-{
-    const int L = (int)c->layers.size();
-    const size_t fc_stride = 2 * (c->n1 ? c->n1 : 1);
-    layer_sweeps(c, w, st, 0, g, L > 1 ? w.fc[1] : nullptr, fc_stride, L > 1 ? c->layers[1].w : 0, L > 1 ? c->layers[1].h : 0,
-                 flow_out, 2 * c->n0);
+    return MAV_OK;
 }
 
 extern "C" int mav_farneback_dev(mav_ctx* c, const uint8_t* prev, const uint8_t* next, int batch, float* flow)
@@ -953,45 +936,53 @@ extern "C" int mav_farneback_dev(mav_ctx* c, const uint8_t* prev, const uint8_t*
     if (!c || !prev || !next || !flow) return fail(MAV_ERR_ARG, "mav_farneback: NULL argument");
     if (batch < 1 || batch > c->max_batch) return fail(MAV_ERR_ARG, "batch %d outside [1, %d]", batch, c->max_batch);
     HIPCHK(hipSetDevice(c->device));
-    // Option "pipeline" (off by default): two streams, two work sets -- the finest layer's sweeps (75 % of the time; one pair per
-    // launch, bound by the latency of a tile and by the Infinity Cache) of group i run on the compute stream while group i + 1
-    // is prepared on the preparation stream, its kernels filling the slots the sweeps' second, partial round of workgroups
-    // leaves idle.  Measured on MI355X: 29.1 vs 28.5 ms per 64 pairs at 1080p, 34.1 vs 33.3 ms per 16 pairs at 4K -- the
-    // preparation's HBM streams evict part of the sweeping pair's working set from the Infinity Cache and cost the sweeps more
-    // than the filled slots return.  Kept switchable (parity-green either way).  Events order the two streams:
-    // a set is prepared only after the sweeps that last used it (fine_done), swept only after its preparation (prep_done), and
-    // the preparation stream starts behind everything already enqueued on the compute stream (call_begin).  Per-kernel
-    // profiling runs everything on the compute stream so that each launch is timed alone.
     // A frame SEQUENCE -- the caller's two batches are views of one run of batch + 1 consecutive frames, next = prev + one frame,
     // which is how a video goes through the reference's loop (src/farneback.py:76-80 with prevgray = the last call's frame) -- has
     // every inner frame in two pairs.  Each group then blurs and expands its g + 1 frames once instead of 2 g (same arithmetic per
     // frame: the flow is bit-identical to the two-batch form; tests/test_gpu_flow.py).  Option "share_frames" = 0 switches it off.
     const bool seq = c->share_frames && next == prev + c->n0;
-    const bool pipe = c->pipeline && c->nsets == 2 && batch > c->group && !c->profiling;
-    if (pipe) {
-        HIPCHK(hipEventRecord(c->call_begin, c->stream));
-        HIPCHK(hipStreamWaitEvent(c->prep_stream, c->call_begin, 0));
-    }
-    int gi = 0;
-    for (int g0 = 0; g0 < batch; g0 += c->group, gi++) {
+    for (int g0 = 0; g0 < batch; g0 += c->group) {
         const int g = batch - g0 < c->group ? batch - g0 : c->group;
-        const int set = pipe ? (gi & 1) : 0;
-        mav_ctx::WorkSet& w = c->ws[set];
-        const hipStream_t ps = pipe ? c->prep_stream : c->stream;
-        if (pipe && gi >= 2) HIPCHK(hipStreamWaitEvent(ps, c->fine_done[set], 0));
-        prep_group(c, w, ps, prev + (size_t)g0 * c->n0, next + (size_t)g0 * c->n0, g, seq);
-        if (pipe) {
-            HIPCHK(hipEventRecord(c->prep_done[set], ps));
-            HIPCHK(hipStreamWaitEvent(c->stream, c->prep_done[set], 0));
-        }
-        fine_group(c, w, c->stream, g, flow + (size_t)g0 * 2 * c->n0);
-        if (pipe) HIPCHK(hipEventRecord(c->fine_done[set], c->stream));
+        CHK(flow_group(c, prev + (size_t)g0 * c->n0, next + (size_t)g0 * c->n0, g, seq, flow + (size_t)g0 * 2 * c->n0));
         CHK(check_launch("farneback kernels"));
     }
     c->last_flow = flow;
     return MAV_OK;
 }
 extern "C" const float* mav_last_flow_dev(const mav_ctx* c) { return c ? c->last_flow : nullptr; }
+
+// The schedule a call of `batch` pairs takes with the options in effect, as one line of JSON (bench.py prints it and hashes it):
+// every option of mav_set_option, the group split and, per layer, how its sweeps run.
+extern "C" int mav_schedule_info(mav_ctx* c, int batch, char* buf, size_t cap)
+{
+    if (!c || !buf || cap < 2) return fail(MAV_ERR_ARG, "mav_schedule_info: NULL argument");
+    if (batch < 1 || batch > c->max_batch) return fail(MAV_ERR_ARG, "batch %d outside [1, %d]", batch, c->max_batch);
+    std::string o = "{";
+    char t[256];
+    for (const auto& d : kOptions) {
+        long v = 0;
+        option_slot(c, d.name, &v);
+        snprintf(t, sizeof(t), "\"%s\": %ld, ", d.name, v);
+        o += t;
+    }
+    const int g = batch < c->group ? batch : c->group;
+    snprintf(t, sizeof(t), "\"pairs_per_group\": %d, \"layers\": [", g);
+    o += t;
+    static const char* const mode_names[] = {"one stream", "two pairs in flight, band-major", "two sub-groups in flight"};
+    for (int k = 0; k < (int)c->layers.size(); k++) {
+        const Layer& l = c->layers[k];
+        const SweepPlan p = plan_sweeps(c, k, g, l.w % 4 == 0 && c->fb.winsize / 2 == 6);
+        snprintf(t, sizeof(t), "%s{\"layer\": %d, \"w\": %d, \"h\": %d, \"blur\": \"%s\", \"sweeps\": \"%s\", \"pairs_per_launch\": %d, \"bands\": %d}",
+                 k ? ", " : "", k, l.w, l.h,
+                 (l.w == c->W && l.h == c->H) ? "3x3" : (blur_resize_is_fused(c->W, c->H, l.w, l.h, l.ksize) ? "fused" : "two-pass"),
+                 mode_names[p.mode], p.mode == SW_COARSE_TWO ? p.half : (p.mode == SW_TWO_PAIRS ? 1 : p.sub), p.J);
+        o += t;
+    }
+    o += "]}";
+    if (o.size() + 1 > cap) return fail(MAV_ERR_ARG, "mav_schedule_info: buffer of %zu bytes too small (%zu needed)", cap, o.size() + 1);
+    memcpy(buf, o.c_str(), o.size() + 1);
+    return MAV_OK;
+}
 
 // ---- detection ---------------------------------------------------------------------------------------------
 static int ensure_foe_scratch(mav_ctx* c, int N)
@@ -1037,6 +1028,7 @@ static int detect_dev(mav_ctx* c, const float* flow32, const double* flow64, con
 {
     const int W = c->W, H = c->H;
     const double* foe = foe_in;
+    const bool want_phi = tp || phi || mask_fixed || mask_dyn || results || box_out || max_phi_bits;
     if (samples) {
         mav_foe_params f;
         if (fp) f = *fp; else mav_foe_defaults(&f);
@@ -1044,27 +1036,30 @@ static int detect_dev(mav_ctx* c, const float* flow32, const double* flow64, con
         CHK(ensure_foe_scratch(c, f.n_pairs));
         double* fo = foe_out ? foe_out : c->foe_dev;
         ProfScope ps(c, K_FOE);
+        // the candidates kernel also initialises the pair's box accumulators and tickets, the vote's last workgroup writes the FoE:
+        // two launches where round 2 had four (candidates, vote, FoE finalize, box init)
+        int32_t* init_box = want_phi ? c->box_acc : nullptr;
         if (flow32)
             launch_foe_f32(c->stream, flow32, derot, samples, batch, W, H, f.n_pairs, sq_threshold(f.mag_threshold),
-                           sq_threshold_f32(f.mag_threshold), sq_threshold(f.ransac_threshold), c->foe_sc, fo);
+                           sq_threshold_f32(f.mag_threshold), sq_threshold(f.ransac_threshold), c->foe_sc, fo, init_box, max_phi_bits);
         else
             launch_foe_f64(c->stream, flow64, samples, batch, W, H, f.n_pairs, sq_threshold(f.mag_threshold),
-                           sq_threshold(f.ransac_threshold), c->foe_sc, fo);
+                           sq_threshold(f.ransac_threshold), c->foe_sc, fo, init_box, max_phi_bits);
         foe = fo;
     }
-    if (tp || phi || mask_fixed || mask_dyn || results || box_out || max_phi_bits) {
+    if (want_phi) {
         if (!foe) return fail(MAV_ERR_ARG, "phi/mask stage needs a FoE (samples or foe)");
         mav_thr_params t;
         if (tp) t = *tp; else mav_thr_defaults(&t);
-        { ProfScope ps(c, K_MISC); launch_box_init(c->stream, c->box_acc, max_phi_bits, batch); }
-        { ProfScope ps(c, K_PHI);
-          if (flow32)
-              launch_phi_mask_f32(c->stream, flow32, derot, foe, sky, batch, W, H, t, phi, mask_fixed, mask_dyn, c->box_acc, max_phi_bits);
-          else
-              launch_phi_mask_f64(c->stream, flow64, foe, sky, batch, W, H, t, phi, mask_fixed, mask_dyn, c->box_acc, max_phi_bits); }
-        ProfScope ps(c, K_MISC);
-        if (results) launch_finalize(c->stream, c->box_acc, foe, batch, results);
-        if (box_out) launch_box_finalize(c->stream, c->box_acc, batch, box_out);
+        if (!samples) { ProfScope ps(c, K_MISC); launch_box_init(c->stream, c->box_acc, max_phi_bits, c->foe_sc.done, batch); }
+        // the pair's record (box, FoE) is written by the phi kernel's last workgroup of the pair: no finalize launch
+        PhiLaunch pl;
+        pl.done = c->foe_sc.done; pl.results = results; pl.box_out = box_out; pl.screen = c->phi_screen; pl.yloop = c->phi_yloop;
+        ProfScope ps(c, K_PHI);
+        if (flow32)
+            launch_phi_mask_f32(c->stream, flow32, derot, foe, sky, batch, W, H, t, phi, mask_fixed, mask_dyn, c->box_acc, max_phi_bits, pl);
+        else
+            launch_phi_mask_f64(c->stream, flow64, foe, sky, batch, W, H, t, phi, mask_fixed, mask_dyn, c->box_acc, max_phi_bits, pl);
     }
     return check_launch("detection kernels");
 }
@@ -1295,7 +1290,7 @@ extern "C" int mav_bbox(mav_ctx* c, const uint8_t* img, int batch, int32_t* box)
     if (!img || !box) return fail(MAV_ERR_ARG, "mav_bbox: NULL argument");
     DevBuf di, db;
     CHK(di.upload(c, img, c->n0 * batch)); CHK(db.alloc(c, sizeof(int32_t) * 4 * batch));
-    launch_box_init(c->stream, c->box_acc, nullptr, batch);
+    launch_box_init(c->stream, c->box_acc, nullptr, nullptr, batch);
     launch_bbox_u8(c->stream, di.as<uint8_t>(), batch, c->W, c->H, c->i32_scratch, c->box_acc);
     launch_box_finalize(c->stream, c->box_acc, batch, db.as<int32_t>());
     CHK(check_launch("bbox"));
@@ -1619,7 +1614,7 @@ extern "C" int mav_stage_coefficients(mav_ctx* c, int k, float* g, float* xg, fl
     return MAV_OK;
 }
 
-extern "C" int mav_stage_blur_resize(mav_ctx* c, const uint8_t* img, int k, float* out)
+static int stage_blur_resize(mav_ctx* c, const uint8_t* img, int k, bool two_pass, float* out)
 {
     const Layer* l;
     CHK(layer_of(c, k, &l));
@@ -1627,12 +1622,14 @@ extern "C" int mav_stage_blur_resize(mav_ctx* c, const uint8_t* img, int k, floa
     const size_t n = (size_t)l->w * l->h;
     DevBuf di, dout;
     CHK(di.upload(c, img, c->n0)); CHK(dout.alloc(c, n * sizeof(float)));
-    launch_blur_resize(c->stream, di.as<uint8_t>(), c->n0, 1, c->W, c->H, l->w, l->h, blur_of(c, *l), c->ws[0].Htmp, c->htmp_stride,
-                       dout.as<float>(), n);
+    launch_blur_resize(c->stream, di.as<uint8_t>(), nullptr, 0, c->n0, 1, c->W, c->H, l->w, l->h, blur_of(c, *l), c->ws.Htmp, c->htmp_stride,
+                       dout.as<float>(), n, two_pass);
     CHK(check_launch("blur_resize"));
     CHK(download(c, out, dout.p, n * sizeof(float)));
     return mav_sync(c);
 }
+extern "C" int mav_stage_blur_resize(mav_ctx* c, const uint8_t* img, int k, float* out) { return stage_blur_resize(c, img, k, false, out); }
+extern "C" int mav_stage_blur_resize_two_pass(mav_ctx* c, const uint8_t* img, int k, float* out) { return stage_blur_resize(c, img, k, true, out); }
 extern "C" int mav_stage_polyexp(mav_ctx* c, const float* I, int k, float* R)
 {
     const Layer* l;
@@ -1670,7 +1667,7 @@ extern "C" int mav_stage_blur_iter(mav_ctx* c, const float* R0, const float* R1,
     CHK(d0.upload(c, R0, 5 * n * sizeof(float))); CHK(d1.upload(c, R1, 5 * n * sizeof(float)));
     CHK(dm.upload(c, M, 5 * n * sizeof(float))); CHK(dmo.alloc(c, 5 * n * sizeof(float))); CHK(df.alloc(c, 2 * n * sizeof(float)));
     launch_blur_iter(c->stream, dm.as<float>(), dmo.as<float>(), 5 * n, d0.as<float>(), d1.as<float>(), 5 * n, 1, l->w, l->h,
-                     c->fb.winsize, update, 1, df.as<float>(), 2 * n);
+                     c->fb.winsize, update, 1, df.as<float>(), 2 * n, 0, -1, c->strip);
     CHK(check_launch("blur_iter"));
     CHK(download(c, flow, df.p, 2 * n * sizeof(float)));
     if (update) CHK(download(c, M_out, dmo.p, 5 * n * sizeof(float)));

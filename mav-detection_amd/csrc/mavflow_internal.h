@@ -38,9 +38,14 @@ struct DerotParams {  // one pair; Detector.derotate
 
 // ---- flow kernels (kernels_flow.hip) ----------------------------------------------------------------------
 // All take G slots; slot s reads/writes base + s*stride (strides in elements).
-void launch_blur_resize(hipStream_t st, const uint8_t* img, size_t img_stride, int G, int W, int H, int w, int h,
-                        BlurParams bp, float* tmp /* G x H x w scratch for the separable passes */, size_t tmp_stride, float* out,
-                        size_t out_stride);
+// G images from two runs: the first `split` from img, the rest from img2 (same stride); img2 == nullptr: one run.  Layers with a
+// short Gaussian (blur_resize_is_fused) go through one fused kernel and never touch tmp unless two_pass is set.
+void launch_blur_resize(hipStream_t st, const uint8_t* img, const uint8_t* img2, int split, size_t img_stride, int G, int W, int H, int w,
+                        int h, BlurParams bp, float* tmp /* G x H x w scratch for the separable passes */, size_t tmp_stride, float* out,
+                        size_t out_stride, bool two_pass = false);
+bool blur_resize_is_fused(int W, int H, int w, int h, int ksize);
+bool blur_resize_needs_tmp(const uint8_t* img, const uint8_t* img2, size_t img_stride, int W, int H, int w, int h, BlurParams bp,
+                           const float* out, size_t out_stride);
 void launch_polyexp(hipStream_t st, const float* I, size_t I_stride, int G, int w, int h, const PolyCoef& pc, float* R,
                     size_t R_stride);
 // flow_prev == nullptr: zero initial flow. Otherwise flow = resize(prev (ph x pw x 2))*mul, evaluated inline.
@@ -52,7 +57,8 @@ void launch_update_matrices_flow(hipStream_t st, const float* R0, const float* R
                                  size_t f_stride, int G, int w, int h, float* M, size_t M_stride);
 void launch_blur_iter(hipStream_t st, const float* M_in, float* M_out, size_t M_stride, const float* R0, const float* R1,
                       size_t R_stride, int G, int w, int h, int winsize, int do_update, int store_flow, float* flow, size_t f_stride,
-                      int ty0 = 0, int ty1 = -1 /* tile rows [ty0, ty1) of 16 pixel rows; ty1 < 0 = the whole layer */);
+                      int ty0 = 0, int ty1 = -1 /* tile rows [ty0, ty1) of 16 pixel rows; ty1 < 0 = the whole layer */,
+                      int strip = 0 /* width in tiles of the tile order's column strips; 0 = automatic */);
 int blur_iter_tile_rows(int h);                 // 16-pixel tile rows of a layer of height h
 // band launches (ty0 / ty1) are honoured only by the fast sweep kernel: true when launch_blur_iter will take it for these operands
 bool blur_iter_bands_ok(int w, int winsize, size_t M_stride, size_t R_stride, size_t f_stride, const void* M_in, const void* M_out,
@@ -60,30 +66,37 @@ bool blur_iter_bands_ok(int w, int winsize, size_t M_stride, size_t R_stride, si
 // store_flow == 0: the sweep's flow is consumed inside the kernel only (valid when do_update != 0)
 size_t blur_iter_lds_bytes(int winsize);
 const char* blur_iter_prepare(int winsize);   // grants the general sweep kernel its dynamic LDS on the current device
-bool launch_sweep_rc(hipStream_t st, int mode, const float* fin, size_t fin_stride, int pw, int ph, float mul, const float* R0,
-                     const float* R1, size_t R_stride, int G, int w, int h, int winsize, float* fout, size_t fout_stride);
 
 // ---- detection kernels (kernels_detect.hip, compiled with -ffp-contract=off) --------------------------------
 struct FoeScratch {
     double* cand;                  // [B][N][2] compacted candidates
     int* count;                    // [B]
     unsigned long long* best_key;  // [B]
+    unsigned* done;                // [B][2] tickets: [0] workgroups of the vote that have finished, [1] of the phi kernel (both self-resetting)
 };
 // FlowT = float (optionally derotated on the fly) or double (already derotated).
 void launch_foe_f32(hipStream_t st, const float* flow, const DerotParams* derot /*dev, [B] or null*/, const uint32_t* samples,
                     int B, int W, int H, int N, double mag2_thr, float mag2_thr_f32 /* frame-0 pairs */, double dist2_thr,
-                    FoeScratch s, double* foe);
+                    FoeScratch s, double* foe, int32_t* box_acc /* nullable: the pair's accumulators are initialised here too */,
+                    unsigned long long* max_phi_bits /* nullable */);
 void launch_foe_f64(hipStream_t st, const double* flow, const uint32_t* samples, int B, int W, int H, int N, double mag2_thr,
-                    double dist2_thr, FoeScratch s, double* foe);
-// box_acc: [B][4] int32 accumulators (x0 min, y0 min, x1 max, y1 max), initialised by launch_box_init.
-void launch_box_init(hipStream_t st, int32_t* box_acc, unsigned long long* max_phi_bits, int B);
+                    double dist2_thr, FoeScratch s, double* foe, int32_t* box_acc, unsigned long long* max_phi_bits);
+// box_acc: [B][4] int32 accumulators (x0 min, y0 min, x1 max, y1 max), initialised by launch_box_init or by launch_foe_*.
+void launch_box_init(hipStream_t st, int32_t* box_acc, unsigned long long* max_phi_bits, unsigned* done /* FoeScratch::done or null */, int B);
+// How a phi launch ends and is tuned: results / box_out (either may be null) are written by the pair's last workgroup (needs done).
+struct PhiLaunch {
+    unsigned* done = nullptr;
+    mav_result* results = nullptr;
+    int32_t* box_out = nullptr;
+    bool screen = true;      // option "phi_screen"
+    int yloop = 0;           // option "phi_yloop" (0 = automatic)
+};
 void launch_phi_mask_f32(hipStream_t st, const float* flow, const DerotParams* derot, const double* foe, const uint8_t* sky,
                          int B, int W, int H, mav_thr_params thr, double* phi, uint8_t* mask_fixed, uint8_t* mask_dyn,
-                         int32_t* box_acc, unsigned long long* max_phi_bits);
+                         int32_t* box_acc, unsigned long long* max_phi_bits, const PhiLaunch& pl);
 void launch_phi_mask_f64(hipStream_t st, const double* flow, const double* foe, const uint8_t* sky, int B, int W, int H,
                          mav_thr_params thr, double* phi, uint8_t* mask_fixed, uint8_t* mask_dyn, int32_t* box_acc,
-                         unsigned long long* max_phi_bits);
-void launch_finalize(hipStream_t st, const int32_t* box_acc, const double* foe, int B, mav_result* results);
+                         unsigned long long* max_phi_bits, const PhiLaunch& pl);
 void launch_box_finalize(hipStream_t st, const int32_t* box_acc, int B, int32_t* box);
 void launch_derotate(hipStream_t st, const float* flow, const DerotParams* derot, int B, int W, int H, double* out);
 void launch_bbox_u8(hipStream_t st, const uint8_t* img, int B, int W, int H, int* maxv /*[B] scratch*/, int32_t* box_acc);

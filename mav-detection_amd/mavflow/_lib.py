@@ -49,7 +49,7 @@ EXPORTS = [
     "mav_stage_polyexp", "mav_stage_update_matrices", "mav_stage_blur_iter",
     "mav_analyze_pyramid", "mav_pyramid_levels", "mav_pyramid_dims", "mav_optimize_window", "mav_stage_pyramid_level",
     "mav_detect", "mav_detect_dev", "mav_last_flow_dev", "mav_foe_dense_f32", "mav_phi_mask_f32", "mav_stage_coefficients",
-    "mav_stage_phi_mask", "mav_last_masks_tpr_fpr",
+    "mav_stage_phi_mask", "mav_last_masks_tpr_fpr", "mav_get_option", "mav_schedule_info", "mav_stage_blur_resize_two_pass",
 ]
 
 _lib = None
@@ -73,6 +73,8 @@ def load() -> C.CDLL:
     lib.mav_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(FbParams)]
     lib.mav_destroy.argtypes = [C.c_void_p]
     lib.mav_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
+    lib.mav_get_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_long)]
+    lib.mav_schedule_info.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]
     lib.mav_num_layers.argtypes = [C.c_void_p]
     lib.mav_layer_dims.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4
     vp = C.c_void_p
@@ -125,6 +127,7 @@ def load() -> C.CDLL:
     lib.mav_comm_destroy.argtypes = [vp]
     lib.mav_allgather_results.argtypes = [vp, vp, vp, C.c_size_t, vp]
     lib.mav_stage_blur_resize.argtypes = [vp, vp, C.c_int, vp]
+    lib.mav_stage_blur_resize_two_pass.argtypes = [vp, vp, C.c_int, vp]
     lib.mav_stage_polyexp.argtypes = [vp, vp, C.c_int, vp]
     lib.mav_stage_update_matrices.argtypes = [vp, vp, vp, vp, C.c_int, vp]
     lib.mav_stage_blur_iter.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp]
@@ -276,6 +279,18 @@ class Context:
     # -- introspection ---------------------------------------------------------------------------------------
     def set_option(self, name: str, value: int):
         check(self.lib.mav_set_option(self.h, name.encode(), int(value)))
+
+    def get_option(self, name: str) -> int:
+        v = C.c_long()
+        check(self.lib.mav_get_option(self.h, name.encode(), C.byref(v)))
+        return v.value
+
+    def schedule_info(self, batch: int) -> dict:
+        """The schedule a call of `batch` pairs takes with the options in effect (every option, group split, per-layer plan)."""
+        import json
+        buf = C.create_string_buffer(8192)
+        check(self.lib.mav_schedule_info(self.h, int(batch), buf, len(buf)))
+        return json.loads(buf.value.decode())
 
     def num_layers(self) -> int:
         return self.lib.mav_num_layers(self.h)
@@ -612,11 +627,12 @@ class Context:
         check(self.lib.mav_stage_coefficients(self.h, k, _ptr(g), _ptr(xg), _ptr(xxg), _ptr(ig), _ptr(blur)))
         return dict(g=g, xg=xg, xxg=xxg, ig=ig, blur=blur)
 
-    def stage_blur_resize(self, img, k):
+    def stage_blur_resize(self, img, k, two_pass=False):
         img = _arr(img, np.uint8, (self.H, self.W), "img")
         w, h, _, _ = self.layer_dims(k)
         out = np.empty((h, w), np.float32)
-        check(self.lib.mav_stage_blur_resize(self.h, _ptr(img), k, _ptr(out)))
+        fn = self.lib.mav_stage_blur_resize_two_pass if two_pass else self.lib.mav_stage_blur_resize
+        check(fn(self.h, _ptr(img), k, _ptr(out)))
         return out
 
     def stage_polyexp(self, I, k):

@@ -5,6 +5,8 @@ Tolerances (floating point; the CPU path mixes f32 storage with f64 accumulators
   stages    absolute, stated per test
   flow      end-point error vs the oracle: mean <= 1e-2 px, p99.9 <= 1e-1 px   (north_star "stated EPE tolerance")
 PARITY UNPINNED vs cv2 itself: OpenCV is not installable here (see oracle/farneback_oracle.c)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -47,6 +49,27 @@ def test_blur_resize(ctx640, fb_oracle, pair640, k):
     got = ctx640.stage_blur_resize(pair640[0], k)
     exp = fb_oracle.blur_resize(pair640[0], w, h, ks, sigma)
     np.testing.assert_allclose(got, exp, rtol=0, atol=2e-4)
+
+
+@pytest.mark.parametrize("size,levels", [((640, 480), 1), ((1920, 1080), 1), ((1000, 562), 1), ((333, 227), 1), ((3840, 2160), 5)])
+def test_fused_blur_resize_equals_the_two_pass_form(mav, fb_oracle, size, levels):
+    """Layers with a short Gaussian (ksize <= 13) go through ONE kernel that keeps the horizontal pass in LDS; the separable
+    two-pass form (H x w scratch in memory) stays for the long ones.  Same functions, same tap order: bit-identical layer images,
+    interior and borders, ragged sizes, noise as well as texture -- and both inside the oracle's tolerance."""
+    from mavflow import _lib
+    W, H = size
+    rng = np.random.default_rng(5)
+    imgs = [synth.make_pair(W, H, 3)[0], rng.integers(0, 256, (H, W), dtype=np.uint8)]
+    with _lib.Context(W, H, 1, _lib.fb_defaults(levels=levels)) as c:
+        fused_layers = [l["layer"] for l in c.schedule_info(1)["layers"] if l["blur"] == "fused"]
+        assert fused_layers == ([1] if levels == 1 else [1, 2])
+        for k in range(1, c.num_layers()):
+            w, h, sigma, ks = c.layer_dims(k)
+            for img in imgs:
+                a, b = c.stage_blur_resize(img, k), c.stage_blur_resize(img, k, two_pass=True)
+                assert np.array_equal(a, b), (k, int((a != b).sum()))
+                if W * H <= 1920 * 1080:
+                    np.testing.assert_allclose(a, fb_oracle.blur_resize(img, w, h, ks, sigma), rtol=0, atol=2e-4)
 
 
 @pytest.mark.parametrize("k", [0, 1])
@@ -170,19 +193,6 @@ def test_shape_errors(ctx640):
         ctx640.farneback(np.zeros((5, 480, 640), np.uint8), np.zeros((5, 480, 640), np.uint8))   # batch > max_batch
 
 
-def test_recompute_sweeps_give_the_same_flow(mav, fb_oracle):
-    """Option "recompute" (M rebuilt inside every sweep instead of stored): the same algebra with differently contracted
-    f32 operations -- equal to rounding noise, and inside the oracle tolerance on its own."""
-    from mavflow import _lib
-    prev, nxt = synth.make_batch(640, 480, 2, distinct=2)
-    with _lib.Context(640, 480, 2) as c:
-        a = c.farneback(prev, nxt)
-        c.set_option("recompute", 1)
-        b = c.farneback(prev, nxt)
-    assert np.abs(a - b).max() < 1e-3, np.abs(a - b).max()
-    _check_flow(b[1], fb_oracle.calc(prev[1], nxt[1]), "recompute")
-
-
 def test_flow_4k_five_layers(mav, fb_oracle):
     """BASELINE config 5 shape: 3840x2160, levels=5 (blur kernels of 95/37/13/5/3 taps), one pair."""
     from mavflow import _lib
@@ -284,21 +294,61 @@ def test_band_major_sweeps_are_bit_identical(mav, size):
         assert np.array_equal(c.farneback(prev, nxt), ref)
 
 
-def test_pipeline_option_gives_the_same_flow(mav):
-    """Option "pipeline" (second work set + preparation stream, off by default because it measured slower) must stay correct:
-    three groups through two alternating work sets, twice, against the single-stream schedule."""
+@pytest.mark.parametrize("size,batch", [((1280, 720), 1), ((1280, 720), 2), ((640, 480), 3), ((1920, 1080), 1), ((1000, 562), 1), ((58, 174), 3)])
+def test_small_groups_give_the_same_results_as_big_ones(mav, size, batch):
+    """Small groups (BASELINE config 2: one 1280x720 pair per call) send prev and next through ONE blur and ONE expansion launch per
+    layer (two runs of images in one grid) where big groups launch per frame set.  Same kernels on the same data: flow, masks and
+    records of a call must not depend on how the batch is cut into groups or calls -- one pair at a time, the whole batch, frames in
+    adjacent or far-apart device buffers -- bit for bit, call after call."""
     from mavflow import _lib
-    W, H, B = 640, 480, 5
-    prev, nxt = synth.make_batch(W, H, B, distinct=3)
-    with _lib.Context(W, H, B) as c:
-        c.set_option("group", 2)                        # groups of 2, 2, 1
-        ref = c.farneback(prev, nxt)
-        c.set_option("pipeline", 1)
-        for _ in range(2):
-            assert np.array_equal(c.farneback(prev, nxt), ref)
-        assert np.array_equal(c.farneback(prev[:2], nxt[:2]), ref[:2])       # a single group: nothing to pipeline
-        c.set_option("pipeline", 0)
-        assert np.array_equal(c.farneback(prev, nxt), ref)
+    W, H = size
+    prev, nxt = synth.make_batch(W, H, batch, distinct=min(batch, 4))
+    smp = np.stack([synth.foe_samples(W, H, b) for b in range(batch)])
+    with _lib.Context(W, H, max(batch, 4)) as c:
+        ref = c.process_batch(prev, nxt, smp)
+        for rep in range(2):
+            for b in range(batch):
+                one = c.process_batch(prev[b:b + 1], nxt[b:b + 1], smp[b:b + 1])
+                for key in ("flow", "mask_fixed", "mask_dyn"):
+                    assert np.array_equal(one[key][0], ref[key][b]), (rep, b, key)
+                assert one["results"].tobytes() == ref["results"][b:b + 1].tobytes()
+        c.set_option("group", 1)
+        out = c.process_batch(prev, nxt, smp)
+        assert np.array_equal(out["flow"], ref["flow"]) and out["results"].tobytes() == ref["results"].tobytes()
+        c.set_option("group", 4)
+        # device pointers, frames in two far-apart allocations (not a frame sequence)
+        dp = c.alloc(prev.nbytes).upload(prev)
+        gap = c.alloc(3 << 20)
+        dn = c.alloc(nxt.nbytes).upload(nxt)
+        out = c.alloc(ref["flow"].nbytes)
+        for rep in range(3):
+            c.farneback_dev(dp.ptr, dn.ptr, batch, out.ptr)
+        c.sync()
+        assert np.array_equal(out.download(np.float32, ref["flow"].shape), ref["flow"])
+        del gap
+
+
+def test_options_are_reported_and_validated(mav):
+    """Every scheduling switch is an option of the context (the library reads no environment variable): set / get round trip,
+    range errors as ValueError, and mav_schedule_info reports the options and the per-layer plan a call will take."""
+    from mavflow import _lib
+    src = "".join(open(os.path.join(os.path.dirname(_lib.__file__), "..", "csrc", f)).read()
+                  for f in ("mavflow.cpp", "kernels_flow.hip", "kernels_detect.hip", "kernels_window.hip"))
+    assert "getenv" not in src
+    with _lib.Context(1920, 1080, 64) as c:
+        info = c.schedule_info(64)
+        assert info["group"] == 16 and info["pairs_in_flight"] == 2 and info["pairs_per_group"] == 16
+        assert [(l["w"], l["h"]) for l in info["layers"]] == [(1920, 1080), (768, 432)]
+        assert info["layers"][0]["sweeps"].startswith("two pairs in flight") and info["layers"][0]["bands"] == 2
+        assert info["layers"][1]["blur"] == "fused" and info["layers"][1]["pairs_per_launch"] == 4
+        for name, v in (("band_mb", 40), ("coarse_half", 3), ("strip", 20), ("phi_yloop", 4), ("phi_screen", 0), ("share_m", 0),
+                        ("coarse_cache_mb", 100), ("bands", 3), ("group_fine", 2)):
+            c.set_option(name, v)
+            assert c.get_option(name) == v
+            assert c.schedule_info(64)[name] == v
+        for name, v in (("pairs_in_flight", 3), ("bands", 9), ("group", 0), ("no_such_option", 1), ("recompute", 1), ("pipeline", 1)):
+            with pytest.raises(ValueError):
+                c.set_option(name, v)
 
 
 def test_winsize_beyond_the_fast_kernel(mav, fb_oracle):
