@@ -25,9 +25,10 @@ for p in (ROOT, os.path.join(ROOT, "mav-detection_amd")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
-ITER_BYTES_UPDATE = 88           # per pixel per sweep: read M 20 + R0 20 + R1 20, write M' 20 + flow 8   
+ITER_BYTES_UPDATE = 88           # SURVEY 8d's model, per pixel per sweep: read M 20 + R0 20 + R1 20, write M' 20 + flow 8
+ITER_BYTES_MOVED = 80            # what the kernel has to move: the flow of an updating sweep is consumed inside the kernel (store_flow = 0)
 ITER_BYTES_LAST = 28             # last sweep of a layer: read M 20, write flow 8
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 
 def b_alg_per_pair(layers, W, H, iters):
@@ -43,14 +44,18 @@ def b_alg_per_pair(layers, W, H, iters):
     return tot + 10 * P0
 
 
-def source_hash():
-    """Identity of the kernel build: sha256 over the library's sources (the GPU box has no .git)."""
+def source_hash(schedule=None):
+    """Identity of what was measured: sha256 over the library's sources (the GPU box has no .git) and, when given, the schedule the
+    call takes (mav_schedule_info: every option in effect plus the per-layer plan) -- the library reads no environment variable, so
+    sources + options determine the launches."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "mav-detection_amd", "csrc")
     for name in sorted(os.listdir(d)):
         if name.endswith((".hip", ".cpp", ".h")) or name == "Makefile":
             h.update(name.encode())
             h.update(open(os.path.join(d, name), "rb").read())
+    if schedule is not None:
+        h.update(json.dumps(schedule, sort_keys=True).encode())
     return h.hexdigest()[:16]
 
 
@@ -147,6 +152,57 @@ def verify_last_step(ctx, prev, nxt, samples, res, mf_buf, md_buf, pairs, levels
                             "against": "cv2" if kind == "reference" else "oracle restatement (cv2 absent)", "pairs": len(pairs)}}
 
 
+def run_config_leg(name, W, H, B, levels, calls, pairs_to_check, verify=True):
+    """One more BASELINE configuration through mav_process_batch_dev in a context of its own (never `value`): `calls` back-to-back
+    calls with the frames resident, HIP-event time on the context's stream and wall time; then the last call's outputs of
+    `pairs_to_check` against the oracle.  Returns the record for the bench line's "configs" object."""
+    import numpy as np
+    from mavflow import _lib, synth
+    ctx = _lib.Context(W, H, B, _lib.fb_defaults(levels=levels))
+    layers = [ctx.layer_dims(k)[:2] for k in range(ctx.num_layers())]
+    prev, nxt = synth.make_batch(W, H, B, distinct=min(B, 4))
+    samples = np.stack([synth.foe_samples(W, H, b) for b in range(B)])
+    d_prev, d_next, d_smp = ctx.alloc(prev.nbytes).upload(prev), ctx.alloc(nxt.nbytes).upload(nxt), ctx.alloc(samples.nbytes).upload(samples)
+    d_res, d_mf, d_md = ctx.alloc(B * _lib.RESULT_DTYPE.itemsize), ctx.alloc(B * W * H), ctx.alloc(B * W * H)
+
+    def call():
+        ctx.process_batch_dev(d_prev.ptr, d_next.ptr, d_smp.ptr, B, d_res.ptr, mf_ptr=d_mf.ptr, md_ptr=d_md.ptr)
+
+    for _ in range(max(3, calls // 20)):
+        call()
+    ctx.sync()
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    for _ in range(calls):
+        call()
+    ev_ms = ctx.timer_stop()
+    ctx.sync()
+    wall_ms = 1e3 * (time.perf_counter() - t0)
+    balg = b_alg_per_pair(layers, W, H, ctx.fb.iterations)
+    per_pair_ms = ev_ms / calls / B
+    out = {"workload": f"{W}x{H}, batch={B}, levels={levels} ({len(layers)} pyramid layers), {calls} back-to-back mav_process_batch_dev calls, frames resident",
+           "ms_per_call_hip_events": round(ev_ms / calls, 4), "ms_per_call_wall": round(wall_ms / calls, 4),
+           "ms_per_pair": round(per_pair_ms, 4), "pairs_per_s": round(B * calls / (wall_ms * 1e-3), 2),
+           "alg_bytes_per_pair": balg, "frac": round(balg / (per_pair_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
+           "frac_is": "whole-pipeline algorithmic bytes (SURVEY 8d) / HIP-event time / 8 TB/s",
+           "schedule": ctx.schedule_info(B)}
+    if verify:
+        res = d_res.download(_lib.RESULT_DTYPE, (B,))
+        v = verify_last_step(ctx, prev, nxt, samples, res, d_mf, d_md, pairs_to_check, levels)
+        out.update({"verified_pairs": v["verified_pairs"], "failed_pairs": v["failed_pairs"], "flow_epe_px": v["flow_epe_px"]})
+    ctx.close()
+    return out
+
+
+def measured_ceilings(ctx):
+    """What this GPU delivers to a plain streaming kernel with the sweeps' 3 reads : 1 write mix (float4 per thread, grid-stride),
+    measured now, in this process (mav_membw_probe): once with a footprint the 256 MB Infinity Cache holds, once far beyond it."""
+    cache = ctx.membw_probe(32 << 20, 40)          # 4 x 32 MB = 128 MB footprint
+    hbm = ctx.membw_probe(1 << 30, 4)              # 4 x 1 GB
+    return {"kernel": "3 reads : 1 write float4 streaming (mav_membw_probe)", "infinity_cache_GBs": round(cache, 1), "hbm_GBs": round(hbm, 1),
+            "footprints_MB": [128, 4096]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -161,6 +217,8 @@ def main():
     ap.add_argument("--cpu-pairs", type=int, default=16, help="pairs in the one-core CPU baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="mav_set_option before the run (A/B experiments); repeatable")
+    ap.add_argument("--no-configs", action="store_true", help="skip the extra BASELINE configuration legs (C2: 1280x720 batch 1; C5 share: 3840x2160, 5 levels, batch 16)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -198,7 +256,11 @@ def main():
         ctx.set_option("group", args.group)
     if args.group_fine >= 0:
         ctx.set_option("group_fine", args.group_fine)
+    for kv in args.opt:
+        name, val = kv.split("=")
+        ctx.set_option(name, int(val))
     layers = [ctx.layer_dims(k)[:2] for k in range(ctx.num_layers())]
+    schedule = ctx.schedule_info(B)                    # every option in effect + the per-layer plan of a B-pair call
 
     prev, nxt = synth.make_batch(W, H, B, distinct=4)
     if rank:                                           # different content per rank
@@ -353,19 +415,22 @@ def main():
         sum_ms = prof["blur_iter"][0] + prof.get("blur_iter_coarse", (0.0, 0))[0]
         launches = prof["blur_iter"][1] + prof.get("blur_iter_coarse", (0, 0))[1]
         iters = ctx.fb.iterations
-        bytes_step = B * sum(w * h * ((iters - 1) * ITER_BYTES_UPDATE + ITER_BYTES_LAST) for (w, h) in layers)
+        npx_step = B * sum(w * h for (w, h) in layers)
+        bytes_moved = npx_step * ((iters - 1) * ITER_BYTES_MOVED + ITER_BYTES_LAST)
+        bytes_survey = npx_step * ((iters - 1) * ITER_BYTES_UPDATE + ITER_BYTES_LAST)
         # Two pairs are in flight on two streams (the library's default schedule): sweep launches overlap pairwise, so the SUM of their
         # durations exceeds the wall time.  The rate is quoted on the time during which the kernel was running at all -- the union of
-        # the launches' intervals (HIP events around every launch on the stream it is launched on) -- i.e. bytes per launch times the
-        # launches in flight over the average launch duration; avg_launch_ms stays the per-launch figure rocprofv3 reports
-        # (tools/trace_union.py computes the same union from a rocprofv3 kernel trace: profiles/<round>/sweep_busy_*.txt).
+        # the launches' intervals (HIP events around every run of launches on the stream they go to); avg_launch_ms stays the
+        # per-launch figure rocprofv3 reports (tools/trace_union.py computes the same union from a rocprofv3 kernel trace).
         ms = busy_ms
-        achieved = bytes_step / (ms * 1e-3) / 1e9
+        achieved = bytes_moved / (ms * 1e-3) / 1e9
+        achieved_survey = bytes_survey / (ms * 1e-3) / 1e9
+        ceil = measured_ceilings(ctx)
         # HBM bytes from the PMC counters: collected by tools/pmc_passes.sh in separate rocprofv3 --pmc runs of THIS command,
-        # corrected as the microarchitecture guide prescribes, committed under profiles/ with the hash of the sources they were
-        # measured on.  Per launch, like `achieved`.  null unless the record matches this build, frame size, batch and schedule.
+        # corrected as the microarchitecture guide prescribes, committed under profiles/ with the hash of the sources and schedule
+        # they were measured on.  Per launch, like `achieved`.  null unless the record matches this build, shape, batch and schedule.
         traffic, traffic_source = None, None
-        want = {"source_hash": source_hash(), "width": W, "height": H, "batch": B, "levels": args.levels, "launches": launches}
+        want = {"source_hash": source_hash(schedule), "width": W, "height": H, "batch": B, "levels": args.levels, "launches": launches}
         pdir = os.path.join(ROOT, "profiles", PROFILE_ROUND)
         why = []
         for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
@@ -375,25 +440,43 @@ def main():
             have = {k: rec_t.get(k) for k in want}
             if have == want:
                 traffic = int(rec_t["hbm_bytes_sweeps_per_step"] / max(launches, 1))
-                traffic_source = (f"profiles/{PROFILE_ROUND}/{name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build, shape and batch "
-                                  f"(memory-side bytes, Infinity-Cache hits included); not measured by this run")
+                traffic_source = (f"profiles/{PROFILE_ROUND}/{name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build, shape, batch and "
+                                  f"schedule (memory-side request bytes: Infinity-Cache hits included, so not DRAM bytes); not measured by this run")
                 break
             why.append(f"{name}: " + ", ".join(f"{k} {have[k]} != {want[k]}" for k in want if have[k] != want[k]))
         if traffic is None:
             traffic_source = "no committed PMC record matches this build / shape (" + "; ".join(why) + "): null" if why else "no PMC record committed: null"
-        roofline = {"bound": "hbm", "kernel": "k_blur_iter_fast (all sweep launches of a step)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+        roofline = {"bound": "hbm", "served_by": "infinity_cache", "kernel": "k_blur_iter_fast (all sweep launches of a step)",
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "achieved_is": "effective algorithmic bandwidth = bytes the sweeps have to move (80 B/px per updating sweep: M, R0, R1 in, M' out -- "
+                                   "the flow of all but a layer's last sweep never leaves the kernel; 28 B/px for the last) / time during which at least one "
+                                   "sweep launch runs.  The schedule keeps every pair's band of M / R0 / R1 inside the 256 MB Infinity Cache between "
+                                   "sweeps, so most of these bytes are served by the cache: this is NOT a DRAM rate, and `frac` compares it with the "
+                                   "8 TB/s HBM spec only because that is the contract's denominator",
+                    "achieved_survey_88B_model": round(achieved_survey, 1), "frac_survey_88B_model": round(achieved_survey / HBM_PEAK_GBS, 4),
+                    "measured_ceiling": ceil,
+                    "frac_of_measured_ceiling": round(achieved / max(ceil["infinity_cache_GBs"], 1e-9), 4),
+                    "traffic": traffic, "traffic_source": traffic_source,
                     "avg_launch_ms": round(sum_ms / max(launches, 1), 4), "launches_per_step": launches,
                     "kernel_busy_ms": round(busy_ms, 3), "kernel_busy_ms_with_per_launch_events": round(busy_per_launch_events, 3),
                     "sum_of_launch_ms": round(sum_ms, 3),
                     "launches_in_flight": round(sum_ms / max(busy_per_launch_events, 1e-9), 2),
-                    "note": "two pairs are in flight on two streams: sweep launches overlap, `achieved` = algorithmic bytes of all sweep launches / "
-                            "kernel_busy_ms (union of the intervals in which the kernel runs, HIP events around every run of launches on each "
-                            "stream); avg_launch_ms / sum_of_launch_ms come from a pass with events around every launch, whose sum exceeds the "
-                            "step by design; the same union from a rocprofv3 kernel trace: profiles/r02/sweep_busy_*.txt",
-                    "alg_bytes_per_launch_avg": int(bytes_step / max(launches, 1)),
+                    "note": "two pairs are in flight on two streams: sweep launches overlap, `achieved` = bytes of all sweep launches / kernel_busy_ms "
+                            "(union of the intervals in which the kernel runs, HIP events around every run of launches on each stream); avg_launch_ms / "
+                            "sum_of_launch_ms come from a pass with events around every launch, whose sum exceeds the step by design; the same union from a "
+                            f"rocprofv3 kernel trace: profiles/{PROFILE_ROUND}/sweep_busy_*.txt",
+                    "alg_bytes_per_launch_avg": int(bytes_moved / max(launches, 1)),
+                    "alg_bytes_per_launch_avg_survey_88B_model": int(bytes_survey / max(launches, 1)),
                     "kernel_share_of_step": round(ms / (1e3 * elapsed / args.steps), 3),
                     "all_kernels_ms": {k: round(v[0], 3) for k, v in prof.items()}}
+
+    # ---- the other BASELINE configurations one GPU can hold (never `value`; outside the headline's timed region) ----
+    configs = None
+    if rank == 0 and world == 1 and not args.no_configs and (W, H, args.levels) == (1920, 1080, 1):
+        d_prev.free(); d_next.free(); d_mf.free(); d_md.free()         # (the headline's buffers are no longer needed)
+        configs = {"C2": run_config_leg("C2", 1280, 720, 1, 1, 400, [0], verify=not args.no_verify),
+                   "C5_share": run_config_leg("C5_share", 3840, 2160, 16, 5, 12, [0, 15], verify=not args.no_verify)}
+        configs["C5_share"]["note"] = "per-GPU share of BASELINE config 5 (batch 128 across 8 GPUs); its CPU baseline (73 s) is not repeated here"
 
     failed = False
     if rank == 0:
@@ -407,11 +490,13 @@ def main():
                "config": {"workload": f"{W}x{H}, batch={B} frame pairs per GPU, Farneback(0.4,{ctx.fb.levels},12,10,8,1.2,0) "
                                       f"+ FoE(1000 pairs) + phi/threshold + box, {len(layers)} pyramid layers",
                           "global_batch": world * B, "parallelism": f"frame-parallel x{world}" + (", all-gather of 32-B records" if world > 1 else ""),
-                          "record_exchange": exchange},
+                          "record_exchange": exchange, "schedule": schedule, "runtime": _lib.runtime_info()},
                "hip_event_ms_per_step": round(ev_ms / args.steps, 3),
                "pipeline_alg_bytes_per_pair": balg,
-               "pipeline_frac_of_hbm_peak": round(value / world * balg / (HBM_PEAK_GBS * 1e9), 4),
-               "source_hash": source_hash()}
+               "pipeline_alg_GBs": round(value / world * balg / 1e9, 1),
+               "pipeline_frac_of_8TBs": round(value / world * balg / (HBM_PEAK_GBS * 1e9), 4),
+               "pipeline_frac_is": "whole-path algorithmic bytes per pair (SURVEY 8d) x pairs/s / 8 TB/s: an effective rate, partly served by the Infinity Cache",
+               "source_hash": source_hash(schedule), "kernel_source_hash": source_hash()}
         if world > 1:
             out["scaling_note"] = "per-GPU work fixed (weak); efficiency is the driver's to compute from the per-N values"
         if h2d_ms:
@@ -421,9 +506,12 @@ def main():
             out["video_sequence"] = video
         if roofline:
             out["roofline"] = roofline
+        if configs:
+            out["configs"] = configs
+            failed = failed or any(c.get("failed_pairs") for c in configs.values())
         if verification:
             out.update({"verified_pairs": verification["verified_pairs"], "verification": {k: v for k, v in verification.items() if k != "verified_pairs"}})
-            failed = bool(verification["failed_pairs"])
+            failed = failed or bool(verification["failed_pairs"])
         if world == 1 and args.cpu_pairs > 0:
             out["cpu_baseline"] = cpu_baseline(prev, nxt, samples, min(args.cpu_pairs, B), args.levels)
         print(json.dumps(out), flush=True)

@@ -225,8 +225,17 @@ int mav_profile_get(mav_ctx*, int* n, const char** names, double* total_ms, long
  * "pairs_in_flight") launches of one class overlap and their summed durations exceed the wall time. */
 int mav_profile_busy(mav_ctx*, const char* names, double* busy_ms);
 
+/* Calibration for the roofline record: GB/s this GPU delivers, now, to a plain streaming kernel with the sweep kernel's mix of
+ * 3 reads : 1 write (four temporary buffers of bytes_per_buffer each, float4 per thread, `reps` timed launches on the context's
+ * stream).  4 x 32 MB stays inside the 256 MB Infinity Cache, 4 x 1 GB does not. */
+int mav_membw_probe(mav_ctx*, size_t bytes_per_buffer, int reps, double* gbs);
+
 /* multi-GPU: gather `bytes_per_rank` bytes from every rank (RCCL ncclAllGather over xGMI) on the context's stream.
  * comm is an ncclComm_t created by the caller (mav_comm_* helpers below wrap RCCL's own bootstrap). */
+/* One line of JSON: the HIP version libmavflow was built with, the HIP runtime / driver versions the process actually runs (in the
+ * multi-GPU bench torch loads its own runtime first and libmavflow binds to it) and RCCL's version once it is loaded (0 before).
+ * mav_comm_init returns MAV_ERR_STATE when the running runtime's major version differs from the build's. */
+int mav_runtime_info(char* buf, size_t cap);
 int mav_comm_unique_id(void* id128 /* 128 bytes out */);
 int mav_comm_init(mav_ctx*, const void* id128, int rank, int nranks, void** comm_out);
 int mav_comm_destroy(void* comm);

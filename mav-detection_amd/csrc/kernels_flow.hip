@@ -1067,3 +1067,20 @@ const char* blur_iter_prepare(int winsize)
     const hipError_t e = hipFuncSetAttribute((const void*)k_blur_iter_generic<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// Calibration (mav_membw_probe, bench.py's `measured_ceiling`): what the memory system delivers to a plain streaming kernel with
+// the sweeps' mix of 3 reads : 1 write (M, R0, R1 in; M' out), one float4 per thread and step, grid-stride.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_probe_r3w1(const float4* __restrict__ a, const float4* __restrict__ b, const float4* __restrict__ c,
+                                                    float4* __restrict__ d, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float4 x = a[i], y = b[i], z = c[i];
+        d[i] = make_float4(x.x + y.x + z.x, x.y + y.y + z.y, x.z + y.z + z.z, x.w + y.w + z.w);
+    }
+}
+void launch_probe_r3w1(hipStream_t st, const float* a, const float* b, const float* c, float* d, size_t n_float4)
+{
+    hipLaunchKernelGGL(k_probe_r3w1, dim3(256 * 8), dim3(256), 0, st, (const float4*)a, (const float4*)b, (const float4*)c, (float4*)d, n_float4);
+}

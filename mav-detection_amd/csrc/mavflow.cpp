@@ -661,6 +661,31 @@ extern "C" int mav_profile_get(mav_ctx* c, int* n, const char** names, double* t
     return MAV_OK;
 }
 
+// Calibration: GB/s of a plain 3-reads-1-write float4 streaming kernel over four buffers of bytes_per_buffer each (the sweeps' mix).
+extern "C" int mav_membw_probe(mav_ctx* c, size_t bytes_per_buffer, int reps, double* gbs)
+{
+    if (!c || !gbs || reps < 1 || bytes_per_buffer < 4096) return fail(MAV_ERR_ARG, "mav_membw_probe: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t bytes = bytes_per_buffer & ~(size_t)4095;
+    float* buf[4] = {nullptr, nullptr, nullptr, nullptr};
+    int rc = MAV_OK;
+    for (int i = 0; i < 4 && rc == MAV_OK; i++)
+        if (hipMalloc(&buf[i], bytes) != hipSuccess) rc = fail(MAV_ERR_OOM, "mav_membw_probe: %zu bytes", bytes);
+    float ms = 0.f;
+    if (rc == MAV_OK) {
+        for (int i = 0; i < 3; i++) hipMemsetAsync(buf[i], 0, bytes, c->stream);
+        for (int w = 0; w < 2; w++) launch_probe_r3w1(c->stream, buf[0], buf[1], buf[2], buf[3], bytes / 16);
+        hipEventRecord(c->t0, c->stream);
+        for (int r = 0; r < reps; r++) launch_probe_r3w1(c->stream, buf[0], buf[1], buf[2], buf[3], bytes / 16);
+        hipEventRecord(c->t1, c->stream);
+        if (hipEventSynchronize(c->t1) != hipSuccess || hipEventElapsedTime(&ms, c->t0, c->t1) != hipSuccess || hipGetLastError() != hipSuccess)
+            rc = fail(MAV_ERR_HIP, "mav_membw_probe: launch or timing failed");
+    }
+    for (float* b : buf) if (b) hipFree(b);
+    if (rc == MAV_OK) *gbs = 4.0 * (double)bytes * reps / (ms * 1e-3) / 1e9;
+    return rc;
+}
+
 static int check_launch(const char* what)
 {
     hipError_t e = hipGetLastError();
@@ -1693,6 +1718,21 @@ static int rccl_sym(const char* name, void** fn)
     if (!*fn) return fail(MAV_ERR_STATE, "RCCL symbol %s missing", name);
     return MAV_OK;
 }
+// Versions at the seam where this library meets a runtime somebody else loaded: in the multi-GPU bench torch has already mapped its
+// own HIP runtime and RCCL (same SONAMEs), so libmavflow -- built by this tree's hipcc -- binds to those.
+typedef int (*nccl_get_version_t)(int*);
+extern "C" int mav_runtime_info(char* buf, size_t cap)
+{
+    if (!buf || cap < 16) return fail(MAV_ERR_ARG, "mav_runtime_info: NULL argument");
+    int rt = 0, drv = 0, nccl = 0;
+    if (hipRuntimeGetVersion(&rt) != hipSuccess) rt = -1;
+    if (hipDriverGetVersion(&drv) != hipSuccess) drv = -1;
+    void* fn = nullptr;
+    if (g_rccl && (fn = dlsym(g_rccl, "ncclGetVersion"))) ((nccl_get_version_t)fn)(&nccl);
+    snprintf(buf, cap, "{\"built_with_hip\": \"%d.%d.%d\", \"hip_runtime\": %d, \"hip_runtime_major\": %d, \"hip_driver\": %d, \"rccl\": %d}",
+             HIP_VERSION_MAJOR, HIP_VERSION_MINOR, HIP_VERSION_PATCH, rt, rt > 0 ? rt / 10000000 : -1, drv, nccl);
+    return MAV_OK;
+}
 extern "C" int mav_comm_unique_id(void* id128)
 {
     if (!id128) return fail(MAV_ERR_ARG, "mav_comm_unique_id: NULL");
@@ -1705,6 +1745,13 @@ extern "C" int mav_comm_init(mav_ctx* c, const void* id128, int rank, int nranks
 {
     if (!c || !id128 || !comm_out) return fail(MAV_ERR_ARG, "mav_comm_init: NULL argument");
     HIPCHK(hipSetDevice(c->device));
+    // the collective runs on this context's stream inside whatever HIP runtime the process loaded first: refuse a runtime of another
+    // major version than the one the kernels' host code was compiled against (launch ABI, stream handles) instead of finding out later
+    int rt = 0;
+    HIPCHK(hipRuntimeGetVersion(&rt));
+    if (rt / 10000000 != HIP_VERSION_MAJOR)
+        return fail(MAV_ERR_STATE, "mav_comm_init: libmavflow was built with HIP %d.%d but the process runs HIP runtime %d (major %d): rebuild against "
+                    "the runtime the launcher loads", HIP_VERSION_MAJOR, HIP_VERSION_MINOR, rt, rt / 10000000);
     void* fn;
     CHK(rccl_sym("ncclCommInitRank", &fn));
     uid128 id;

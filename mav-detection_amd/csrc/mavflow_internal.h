@@ -67,6 +67,8 @@ bool blur_iter_bands_ok(int w, int winsize, size_t M_stride, size_t R_stride, si
 size_t blur_iter_lds_bytes(int winsize);
 const char* blur_iter_prepare(int winsize);   // grants the general sweep kernel its dynamic LDS on the current device
 
+void launch_probe_r3w1(hipStream_t st, const float* a, const float* b, const float* c, float* d, size_t n_float4);   // calibration
+
 // ---- detection kernels (kernels_detect.hip, compiled with -ffp-contract=off) --------------------------------
 struct FoeScratch {
     double* cand;                  // [B][N][2] compacted candidates

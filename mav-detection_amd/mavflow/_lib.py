@@ -50,6 +50,7 @@ EXPORTS = [
     "mav_analyze_pyramid", "mav_pyramid_levels", "mav_pyramid_dims", "mav_optimize_window", "mav_stage_pyramid_level",
     "mav_detect", "mav_detect_dev", "mav_last_flow_dev", "mav_foe_dense_f32", "mav_phi_mask_f32", "mav_stage_coefficients",
     "mav_stage_phi_mask", "mav_last_masks_tpr_fpr", "mav_get_option", "mav_schedule_info", "mav_stage_blur_resize_two_pass",
+    "mav_membw_probe", "mav_runtime_info",
 ]
 
 _lib = None
@@ -75,6 +76,8 @@ def load() -> C.CDLL:
     lib.mav_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
     lib.mav_get_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_long)]
     lib.mav_schedule_info.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]
+    lib.mav_runtime_info.argtypes = [C.c_char_p, C.c_size_t]
+    lib.mav_membw_probe.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
     lib.mav_num_layers.argtypes = [C.c_void_p]
     lib.mav_layer_dims.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4
     vp = C.c_void_p
@@ -284,6 +287,12 @@ class Context:
         v = C.c_long()
         check(self.lib.mav_get_option(self.h, name.encode(), C.byref(v)))
         return v.value
+
+    def membw_probe(self, bytes_per_buffer: int, reps: int = 20) -> float:
+        """GB/s of a plain 3-reads-1-write streaming kernel over four buffers of that size (calibration for bench.py's roofline)."""
+        g = C.c_double()
+        check(self.lib.mav_membw_probe(self.h, int(bytes_per_buffer), int(reps), C.byref(g)))
+        return g.value
 
     def schedule_info(self, batch: int) -> dict:
         """The schedule a call of `batch` pairs takes with the options in effect (every option, group split, per-layer plan)."""
@@ -658,6 +667,14 @@ class Context:
         Mo = np.empty((5, h, w), np.float32)
         check(self.lib.mav_stage_blur_iter(self.h, _ptr(R0), _ptr(R1), _ptr(M), k, int(bool(update)), _ptr(flow), _ptr(Mo)))
         return flow, (Mo if update else None)
+
+
+def runtime_info() -> dict:
+    """HIP version of the build, HIP runtime / driver versions of this process, RCCL version once loaded (mav_runtime_info)."""
+    import json
+    buf = C.create_string_buffer(512)
+    check(load().mav_runtime_info(buf, len(buf)))
+    return json.loads(buf.value.decode())
 
 
 def device_count() -> int:

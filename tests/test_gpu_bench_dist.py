@@ -1,0 +1,38 @@
+"""bench.py's distributed code path on one GPU: torch.distributed process group (nccl = RCCL) at world size 1 -> ncclUniqueId
+broadcast -> mav_comm_init -> the record all-gather inside every step on the context's stream (mav_allgather_results) -> the
+gathered block checked against the local records.  This is the path the driver's 1/2/4/8-GPU scaling run takes; with torch loaded
+first libmavflow.so (built by this tree's hipcc) binds to the HIP runtime and RCCL torch ships, a version seam nothing else
+exercises.  Runs bench.py as a CHILD process (it must own its process group and its GPU context)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_distributed_path_world_size_1():
+    env = dict(os.environ, MAVFLOW_BENCH_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-profile", "--cpu-pairs", "0", "--no-configs"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["steps"] == 2
+    assert d["config"]["record_exchange"].startswith("mav_allgather_results"), d["config"]["record_exchange"]
+    assert d["verified_pairs"] == [0, 63], d.get("verification")
+    rt = d["config"]["runtime"]
+    print("\nruntime seam:", rt)
+    built_major = int(rt["built_with_hip"].split(".")[0])
+    assert rt["hip_runtime_major"] == built_major            # mav_comm_init refuses anything else (MAV_ERR_STATE)
+    assert rt["rccl"] > 0                                     # the library's communicator really went through RCCL
+
+
+def test_comm_init_reports_versions(mav):
+    from mavflow import _lib
+    rt = _lib.runtime_info()
+    assert rt["hip_runtime"] > 0 and rt["hip_runtime_major"] == int(rt["built_with_hip"].split(".")[0])

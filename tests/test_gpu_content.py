@@ -1,0 +1,103 @@
+"""Content robustness of the HIP flow path at 1920x1080: pictures unlike the band-limited texture every other flow test uses.
+
+The GPU path stores and sums in float32 (sliding differences inside a tile) where OpenCV's CPU code -- and the C oracle --
+accumulates the box sums in float64; flat areas, step edges, noise, low contrast and saturation are where that could show.  The
+reference's subject is a small drone against sky (/root/reference/src/processor.py:314-317 sky mask, :333-341 thresholds).
+
+Per case, through the C-ABI (mav_process_batch): flow finite and inside the EPE gate against the C oracle (mean <= 1e-2 px,
+p99.9 <= 1e-1 px; the measured mean / p99.9 / max are printed), and FoE, both masks and the box bit-exact against the numpy
+chain (oracle/foe_oracle.py) evaluated on the GPU's own flow."""
+import numpy as np
+import pytest
+
+from oracle import foe_oracle as fo
+from mavflow import synth
+
+pytestmark = pytest.mark.gpu
+W, H = 1920, 1080
+
+
+def _sky_ground_object(noise_sigma):
+    """sky = constant 200 + sensor noise (independent per frame), textured ground under a radial warp, a 30x40 textured object in
+    the sky moving (6, -3)"""
+    rng = np.random.default_rng(11)
+    f0, f1, _ = synth.make_pair(W, H, 21, patch=False)
+    horizon = int(0.42 * H)
+    out = []
+    obj = rng.integers(30, 226, (30, 40)).astype(np.float64)
+    for i, f in enumerate((f0, f1)):
+        g = f.astype(np.float64)
+        g[:horizon] = 200.0 + rng.normal(0.0, noise_sigma, (horizon, W))
+        x0, y0 = 700 + 6 * i, 200 - 3 * i
+        g[y0:y0 + 30, x0:x0 + 40] = obj
+        out.append(np.clip(np.rint(g), 0, 255).astype(np.uint8))
+    return out[0], out[1]
+
+
+def _blocks():
+    """20-px piecewise-constant blocks, shifted by (2, 1)"""
+    rng = np.random.default_rng(12)
+    small = rng.integers(0, 256, ((H + 19) // 20 + 1, (W + 19) // 20 + 1), dtype=np.uint8)
+    big = np.kron(small, np.ones((20, 20), np.uint8))
+    return big[1:H + 1, 2:W + 2].copy(), big[:H, :W].copy()            # frame1(x, y) = frame0(x - 2, y - 1)
+
+
+def _noise():
+    """uniform noise, shifted by (2, 1)"""
+    rng = np.random.default_rng(13)
+    big = rng.integers(0, 256, (H + 1, W + 2), dtype=np.uint8)
+    return big[1:, 2:].copy(), big[:H, :W].copy()
+
+
+def _low_contrast():
+    """the usual texture at 3 % contrast: +-3.6 grey levels, quantisation dominates"""
+    f0, f1, _ = synth.make_pair(W, H, 22)
+    lo = lambda f: np.rint(127.5 + 0.03 * (f.astype(np.float64) - 127.5)).astype(np.uint8)
+    return lo(f0), lo(f1)
+
+
+def _saturated():
+    """the usual texture at 4x gain: a tenth of the pixels clipped at 0 and a tenth at 255"""
+    f0, f1, _ = synth.make_pair(W, H, 23)
+    hi = lambda f: np.clip(np.rint(127.5 + 4.0 * (f.astype(np.float64) - 127.5)), 0, 255).astype(np.uint8)
+    a, b = hi(f0), hi(f1)
+    assert (a == 0).mean() > 0.05 and (a == 255).mean() > 0.05
+    return a, b
+
+
+CASES = {
+    "sky+ground+object, sky noise sigma 0.5": lambda: _sky_ground_object(0.5),
+    "sky+ground+object, noiseless sky": lambda: _sky_ground_object(0.0),
+    "20-px constant blocks shifted (2, 1)": _blocks,
+    "uniform noise shifted (2, 1)": _noise,
+    "texture at 3 % contrast": _low_contrast,
+    "texture clipped at 0 / 255": _saturated,
+}
+
+
+@pytest.fixture(scope="module")
+def ctx1080(mav):
+    from mavflow import _lib
+    with _lib.Context(W, H, 1) as c:
+        yield c
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_content(ctx1080, fb_oracle, name):
+    f0, f1 = CASES[name]()
+    smp = synth.foe_samples(W, H, 5)[None]
+    out = ctx1080.process_batch(f0[None], f1[None], smp)
+    flow = out["flow"][0]
+    assert np.isfinite(flow).all(), name
+    ref = fb_oracle.calc(f0, f1)
+    e = np.hypot(flow[..., 0] - ref[..., 0], flow[..., 1] - ref[..., 1])
+    print(f"\n{name}: EPE vs the C oracle mean {e.mean():.3e}  p99.9 {np.percentile(e, 99.9):.3e}  max {e.max():.3e}  "
+          f"(|flow| max {np.abs(ref).max():.2f} px)")
+    assert e.mean() <= 1e-2, (name, e.mean())
+    assert np.percentile(e, 99.9) <= 1e-1, (name, np.percentile(e, 99.9))
+    chain = fo.run_chain(flow, smp[0])
+    r = out["results"][0]
+    assert tuple(r["foe"]) == tuple(chain["foe"]), name
+    assert np.array_equal(out["mask_fixed"][0], chain["fixed"]), name
+    assert np.array_equal(out["mask_dyn"][0], chain["total"]), name
+    assert tuple(r["box"]) == tuple(chain["box"]), name

@@ -5,8 +5,8 @@ set -u
 export TMPDIR=/tmp
 out=$1; mkdir -p "$out"
 B4K="--width 3840 --height 2160 --levels 5 --batch 16"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt1080" -- python3 bench.py --steps 5 --warmup 2 --cpu-pairs 0 --no-verify > "$out/kt1080.json" 2> "$out/kt1080.err" || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt4k" -- python3 bench.py --steps 5 --warmup 2 --cpu-pairs 0 --no-verify $B4K > "$out/kt4k.json" 2> "$out/kt4k.err" || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt1080" -- python3 bench.py --steps 5 --warmup 2 --cpu-pairs 0 --no-configs --no-verify > "$out/kt1080.json" 2> "$out/kt1080.err" || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt4k" -- python3 bench.py --steps 5 --warmup 2 --cpu-pairs 0 --no-configs --no-verify $B4K > "$out/kt4k.json" 2> "$out/kt4k.err" || exit 1
 tools/pmc_passes.sh "$out/pmc1080" --batch 64 > "$out/pmc1080.log" 2>&1 || exit 1
 tools/pmc_passes.sh "$out/pmc4k" $B4K > "$out/pmc4k.log" 2>&1 || exit 1
 python3 tools/make_traffic.py "$out/pmc1080" "$out/traffic.json" --batch 64 > /dev/null || exit 1
