@@ -209,6 +209,10 @@ int mav_memcpy_d2h(mav_ctx*, void* dst, const void* src, size_t bytes);
 int mav_host_alloc(mav_ctx*, size_t bytes, void** out);
 int mav_host_free(mav_ctx* /* may be NULL: the memory may outlive its context */, void* p);
 int mav_upload_async(mav_ctx*, void* dst_dev, const void* src_host, size_t bytes);
+/* The same copy WITHOUT the wait for the compute stream: for a destination no enqueued work touches (the other buffer set).  With
+ * mav_upload_async the order  process_batch_dev(set A) ; upload_async(set B)  makes the copy wait for batch A -- correct, but the
+ * overlap is gone; this form overlaps in either order.  Overwriting a buffer that enqueued work still reads is the caller's bug. */
+int mav_upload_async_unordered(mav_ctx*, void* dst_dev, const void* src_host, size_t bytes);
 int mav_upload_fence(mav_ctx*);
 
 /* HIP-event timing on the context's stream (bench.py): start/stop bracket enqueued work; stop synchronises. */

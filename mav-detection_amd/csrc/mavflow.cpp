@@ -566,6 +566,14 @@ extern "C" int mav_upload_async(mav_ctx* c, void* dst_dev, const void* src_host,
     HIPCHK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->copy_stream));
     return MAV_OK;
 }
+extern "C" int mav_upload_async_unordered(mav_ctx* c, void* dst_dev, const void* src_host, size_t bytes)
+{
+    if (!c || !dst_dev || !src_host) return fail(MAV_ERR_ARG, "mav_upload_async_unordered: NULL argument");
+    // no wait for the compute stream: the caller vouches that nothing enqueued so far touches dst_dev (a buffer set that work
+    // already enqueued does not use), so the copy overlaps that work whatever the order of the two calls
+    HIPCHK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->copy_stream));
+    return MAV_OK;
+}
 extern "C" int mav_upload_fence(mav_ctx* c)
 {
     if (!c) return fail(MAV_ERR_ARG, "mav_upload_fence: NULL context");

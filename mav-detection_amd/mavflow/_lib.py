@@ -50,7 +50,7 @@ EXPORTS = [
     "mav_analyze_pyramid", "mav_pyramid_levels", "mav_pyramid_dims", "mav_optimize_window", "mav_stage_pyramid_level",
     "mav_detect", "mav_detect_dev", "mav_last_flow_dev", "mav_foe_dense_f32", "mav_phi_mask_f32", "mav_stage_coefficients",
     "mav_stage_phi_mask", "mav_last_masks_tpr_fpr", "mav_get_option", "mav_schedule_info", "mav_stage_blur_resize_two_pass",
-    "mav_membw_probe", "mav_runtime_info",
+    "mav_membw_probe", "mav_runtime_info", "mav_upload_async_unordered",
 ]
 
 _lib = None
@@ -119,6 +119,7 @@ def load() -> C.CDLL:
     lib.mav_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     lib.mav_host_free.argtypes = [vp, vp]
     lib.mav_upload_async.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.mav_upload_async_unordered.argtypes = [vp, vp, vp, C.c_size_t]
     lib.mav_upload_fence.argtypes = [vp]
     lib.mav_timer_start.argtypes = [vp]
     lib.mav_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
@@ -190,16 +191,24 @@ class _PinnedPool:
     pool when the last numpy array or view over them is garbage-collected.
     Module-level: a block lent out survives the context that allocated it."""
 
+    CAP_BYTES = 2 << 30                                  # idle blocks kept for re-use: at most this much page-locked memory in all
+
     def __init__(self):
         self.free = {}                                   # nbytes -> [ptr, ...]
+        self.idle_bytes = 0
+        self.stamp = {}                                  # nbytes -> tick of the last use of that size (least recently used goes first)
+        self.tick = 0
 
     def empty(self, ctx: "Context", shape, dtype) -> np.ndarray:
         import weakref
         dtype = np.dtype(dtype)
         nbytes = max(1, int(np.prod(shape)) * dtype.itemsize)
+        self.tick += 1
+        self.stamp[nbytes] = self.tick
         lst = self.free.get(nbytes)
         if lst:
             ptr = lst.pop()
+            self.idle_bytes -= nbytes
         else:
             p = C.c_void_p()
             check(ctx.lib.mav_host_alloc(ctx.h, nbytes, C.byref(p)))
@@ -211,11 +220,22 @@ class _PinnedPool:
         return np.ctypeslib.as_array(owner).view(dtype)[:int(np.prod(shape))].reshape(shape)
 
     def _give(self, nbytes, ptr):
+        """A block comes back.  At most 4 idle blocks per size and CAP_BYTES idle in all: a long-running caller with changing batch
+        sizes (a 64-pair 1080p flow block is 1 GB) must not pile up page-locked memory -- blocks of the least recently used sizes
+        are released first, then the returning block itself if it alone exceeds the cap."""
         lst = self.free.setdefault(nbytes, [])
-        if len(lst) < 4:
-            lst.append(ptr)
-        else:
+        if len(lst) >= 4 or nbytes > self.CAP_BYTES:
             load().mav_host_free(None, ptr)
+            return
+        lst.append(ptr)
+        self.idle_bytes += nbytes
+        for size in sorted(self.free, key=lambda k: self.stamp.get(k, 0)):
+            while self.idle_bytes > self.CAP_BYTES and self.free[size] and not (size == nbytes and len(self.free[size]) == 1):
+                load().mav_host_free(None, self.free[size].pop())
+                self.idle_bytes -= size
+        if self.idle_bytes > self.CAP_BYTES:             # only this block's own size is left
+            load().mav_host_free(None, lst.pop())
+            self.idle_bytes -= nbytes
 
 
 _pinned = _PinnedPool()
@@ -324,8 +344,11 @@ class Context:
         out[...] = a
         return out
 
-    def upload_async(self, dst: DeviceBuffer, src: np.ndarray):
-        check(self.lib.mav_upload_async(self.h, dst.ptr, _ptr(src), src.nbytes))
+    def upload_async(self, dst: DeviceBuffer, src: np.ndarray, ordered: bool = True):
+        """Copy on the copy stream.  ordered (default): behind everything enqueued on the compute stream so far (safe for a buffer
+        set an earlier batch may still read); ordered=False: no wait -- for a destination no enqueued work touches."""
+        fn = self.lib.mav_upload_async if ordered else self.lib.mav_upload_async_unordered
+        check(fn(self.h, dst.ptr, _ptr(src), src.nbytes))
 
     def upload_fence(self):
         check(self.lib.mav_upload_fence(self.h))
@@ -519,8 +542,14 @@ class Context:
     def detect(self, flow, samples, omega=None, dt=None, sky=None, foe_params=None, thr_params=None, want_phi=False,
                want_masks=True, frame0=None):
         """processor.py:305-341 from the reference's own flow seam: a float32 (B, H, W, 2) field (Dataset.get_flow_uv) in,
-        derotation -> FoE -> phi -> masks -> box on the device, masks and records out."""
-        flow = np.asarray(flow, np.float32)
+        derotation -> FoE -> phi -> masks -> box on the device, masks and records out.
+        The field must BE float32 (what .flo files and Farneback give): the reference evaluates a float64 field in float64 from the
+        start, which this fused call does not do -- such input goes through derotate / foe_dense / phi_mask (the float64 kernels),
+        as Processor.run_detection does by itself."""
+        flow = np.asarray(flow)
+        if flow.dtype != np.float32:
+            raise TypeError(f"detect() takes a float32 flow field, got {flow.dtype}: narrowing would change FoE and masks against the "
+                            "reference; use derotate / foe_dense / phi_mask for float64 fields")
         flow = flow[None] if flow.ndim == 3 else flow
         B = flow.shape[0]
         flow = _arr(flow, np.float32, (B, self.H, self.W, 2), "flow")

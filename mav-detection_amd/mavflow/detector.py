@@ -58,7 +58,13 @@ class Detector:
         dt = self.dataset.get_delta_time(current_frame_index)
         omega = np.asarray(self.dataset.get_angular_difference(previous_frame_index, current_frame_index), np.float64) / dt
         W, H = self.dataset.capture_size[0], self.dataset.capture_size[1]
-        return im_helpers._ctx(W, H).derotate(np.asarray(flow_uv, np.float32), omega, dt)[0]
+        flow_uv = np.asarray(flow_uv)
+        if flow_uv.dtype != np.float32:
+            # a float64 field (no dataset of the reference produces one: .flo files and Farneback are float32) keeps its precision:
+            # the reference's own numpy arithmetic on the host, not the float32-input kernel
+            rows, cols = np.mgrid[0:flow_uv.shape[0], 0:flow_uv.shape[1]]
+            return self.derotate_at(previous_frame_index, current_frame_index, flow_uv.astype(np.float64, copy=False), rows, cols)
+        return im_helpers._ctx(W, H).derotate(flow_uv, omega, dt)[0]
 
     def derotate_at(self, previous_frame_index: int, current_frame_index: int, flow_values: np.ndarray, rows: np.ndarray,
                     cols: np.ndarray) -> np.ndarray:

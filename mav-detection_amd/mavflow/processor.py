@@ -28,6 +28,7 @@ class SyntheticDataset:
                  dangle=(0.0, 0.0, 0.0), seed: int = 0):
         self.capture_size = (W, H)
         self.resolution = np.array([W, H])
+        self.constant_segmentation = True                # one segmentation image for all frames (Processor derives it once)
         self.N = N
         self.sequence = f"synthetic-{seed}"
         self.use_farneback = use_farneback
@@ -122,6 +123,8 @@ class Processor:
         self.frame_index, self.start_frame = 0, 100
         self.is_exiting = False
         self.focus_of_expansion = FocusOfExpansion(self.detector.lucas_kanade)
+        self.flow_uv = None
+        self._derot, self._derot_frame = None, 0
 
     def is_active(self) -> bool:
         return self.frame_index < self.dataset.N - 1 and not self.is_exiting
@@ -151,23 +154,43 @@ class Processor:
         return r
 
     def _segmentation(self, i: int):
-        """Channel 0 of the dataset's segmentation image, contiguous, with the coordinates of its drone pixels (> 127).  Derived
-        once per image OBJECT: a dataset that hands out the same array every frame (SyntheticDataset) pays once, one that reads
-        a new PNG per frame pays per frame, as the reference's loop does (processor.py:332,344-345)."""
+        """Channel 0 of the dataset's segmentation image, contiguous, with the coordinates of its drone pixels (> 127) and the
+        centre of its bounding box (processor.py:332,344-347).  Derived per frame, as the reference's loop does, unless the dataset
+        DECLARES its segmentation constant (attribute `constant_segmentation`, SyntheticDataset): then once.  (Caching on the
+        array's identity alone would hand a dataset that refills one preallocated array the first frame's pixels for ever.)"""
         seg3 = self.dataset.get_segmentation(i)
-        if getattr(self, "_seg_key", None) is not seg3:
-            seg = np.ascontiguousarray(seg3[..., 0])
-            rows, cols = np.nonzero(seg > 127)
-            self._seg_key, self._seg_val = seg3, (seg, rows, cols)
+        if getattr(self.dataset, "constant_segmentation", False) and getattr(self, "_seg_val", None) is not None:
+            return self._seg_val
+        seg = np.ascontiguousarray(seg3[..., 0])
+        rows, cols = np.nonzero(seg > 127)
+        self._seg_val = (seg, rows, cols)
+        self._center = None
         return self._seg_val
 
     def _gt_center(self, segmentation: np.ndarray):
-        """get_simple_bounding_box(segmentation).get_center() (processor.py:346-347); datasets whose segmentation image is one
-        constant object (SyntheticDataset) have it computed once."""
-        key = id(segmentation)
-        if getattr(self, "_center_key", None) != key:
-            self._center_key, self._center = key, im_helpers.get_simple_bounding_box(segmentation).get_center()
+        """get_simple_bounding_box(segmentation).get_center() (processor.py:346-347) of the image _segmentation() last derived.
+        Evaluated on first use, AFTER the detection call's masks have been counted on the device: the box is a device call on the
+        same context and would displace them."""
+        if self._center is None:
+            self._center = im_helpers.get_simple_bounding_box(segmentation).get_center()
         return self._center
+
+    # The reference's loop also leaves flow_uv_derotated and flow_mag behind (processor.py:306-307).  The fused call never forms
+    # them on the host; they are derived on first access from the frame's flow, through the same shims the staged loop uses.
+    @property
+    def flow_uv_derotated(self):
+        if self._derot is None and self.flow_uv is not None:
+            self._derot = self.detector.derotate(self._derot_frame - self.frame_step_size, self._derot_frame, self.flow_uv)
+        return self._derot
+
+    @flow_uv_derotated.setter
+    def flow_uv_derotated(self, v):
+        self._derot = v
+
+    @property
+    def flow_mag(self):
+        d = self.flow_uv_derotated
+        return None if d is None else im_helpers.get_magnitude(d)
 
     def _rates(self, i: int):
         dt = self.dataset.get_delta_time(i)
@@ -187,6 +210,12 @@ class Processor:
             self.flow_uv = self.dataset.get_flow_uv(i)
             if self.flow_uv is None:
                 raise ValueError("Could not load flow field.")
+            self._derot, self._derot_frame = None, i
+            if np.asarray(self.flow_uv).dtype != np.float32:
+                # a float64 field is evaluated in float64 from the start by the reference: the fused float32 call would narrow
+                # it, so this frame goes through the float64 kernels (the staged calls)
+                self._staged_frame(i)
+                continue
             self.sky_mask = self.dataset.get_sky_segmentation(i)
             sky = self.dataset.validate_sky_segment(self.sky_mask, utils.assert_type(self.dataset.get_depth(i)))
             rand1 = np.zeros((2000, 2), dtype=np.uint32)                 # focus_of_expansion.py:69-71
@@ -214,17 +243,22 @@ class Processor:
             self.flow_uv = self.dataset.get_flow_uv(i)
             if self.flow_uv is None:
                 raise ValueError("Could not load flow field.")
-            self.flow_uv_derotated = self.detector.derotate(i - self.frame_step_size, i, self.flow_uv)
-            self.sky_mask = self.dataset.get_sky_segmentation(i)
-            sky = self.dataset.validate_sky_segment(self.sky_mask, utils.assert_type(self.dataset.get_depth(i)))
-            foe = self.focus_of_expansion.get_FOE_dense(self.flow_uv_derotated)
-            fixed, total = self.focus_of_expansion.get_masks(self.flow_uv_derotated, foe, self.sky_mask)
-            self.estimate_fixed, self.total_mask = fixed, total
-            r = self._fill_result(i, foe, fixed, total, sky)
-            self.detection_results[i] = r
-            self.config.results[i] = r
-            self.frame_index += 1
+            self._staged_frame(i)
         return self.detection_results
+
+    def _staged_frame(self, i: int) -> None:
+        """One frame through the reference-named calls (processor.py:306-341), flow already in self.flow_uv."""
+        self._derot_frame = i
+        self.flow_uv_derotated = self.detector.derotate(i - self.frame_step_size, i, self.flow_uv)
+        self.sky_mask = self.dataset.get_sky_segmentation(i)
+        sky = self.dataset.validate_sky_segment(self.sky_mask, utils.assert_type(self.dataset.get_depth(i)))
+        foe = self.focus_of_expansion.get_FOE_dense(self.flow_uv_derotated)
+        fixed, total = self.focus_of_expansion.get_masks(self.flow_uv_derotated, foe, self.sky_mask)
+        self.estimate_fixed, self.total_mask = fixed, total
+        r = self._fill_result(i, foe, fixed, total, sky)
+        self.detection_results[i] = r
+        self.config.results[i] = r
+        self.frame_index += 1
 
     def run_detection_batched(self, batch: int = 8) -> Dict[int, FrameResult]:
         """The same loop with frame pairs in flight `batch` at a time through the fused entry point (frames -> flow ->

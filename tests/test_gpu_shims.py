@@ -153,6 +153,84 @@ def test_processor_loops_agree_with_the_oracle(mav):
             (ref["box"][0], ref["box"][1], ref["box"][2] - ref["box"][0], ref["box"][3] - ref["box"][1])
 
 
+def test_float64_flow_keeps_its_precision_and_loop_attributes_exist(mav):
+    """A dataset whose get_flow_uv returns float64 is evaluated in float64 from the start by the reference (derotate, get_FOE_dense and
+    get_phi all promote): Context.detect() refuses to narrow it, Processor.run_detection() routes such frames through the float64
+    kernels, and both loops then agree with the numpy chain on the float64 field.  The loop also exposes flow_uv_derotated / flow_mag
+    (processor.py:306-307), derived on first access; and a dataset that refills ONE segmentation array per frame is followed."""
+    from mavflow import _lib
+    from mavflow.processor import Processor, SyntheticDataset
+    from mavflow.run_config import RunConfig
+    W, H, N = 320, 240, 4
+
+    class F64Dataset(SyntheticDataset):
+        constant_segmentation = False
+
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            self.constant_segmentation = False
+            self._one_seg = np.zeros((H, W, 3), np.uint8)
+
+        def get_flow_uv(self, i):
+            f = self.get_gt_of(i).astype(np.float64)
+            return f + 1e-9 * np.arange(W)[None, :, None]           # not representable in float32
+
+        def get_segmentation(self, i):                                # the SAME array object, refilled per frame
+            self._one_seg[...] = 0
+            self._one_seg[10 * (i + 1):10 * (i + 1) + 24, 40:64] = 255
+            return self._one_seg
+
+    def make():
+        ds = F64Dataset(W, H, N, use_farneback=False, dangle=(0.004, -0.002, 0.001))
+        cfg = RunConfig(logging.getLogger("t"), ds, "", False, False, False, True, False, False, "FLOW_FOE_CLUSTERING")
+        np.random.seed(5)
+        return Processor(cfg), ds
+    p1, ds1 = make()
+    res = p1.run_detection()
+    p2, _ = make()
+    res_s = p2.run_detection_staged()
+    assert sorted(res) == sorted(res_s) == [0, 1, 2]
+    np.random.seed(5)
+    make()
+    for i in range(N - 1):
+        assert vars(res[i]) == vars(res_s[i]), i
+        smp = np.zeros((2000, 2), np.uint32)
+        smp[:, 0] = np.random.randint(0, H, 2000); smp[:, 1] = np.random.randint(0, W, 2000)
+        ref = fo.run_chain(ds1.get_flow_uv(i), smp, ds1.dangle / ds1.dt, ds1.dt, None, current_frame_index=i)
+        assert res[i].foe_dense == ref["foe"], i
+        assert res[i].center_phi != res[(i + 1) % (N - 1)].center_phi           # the segmentation moved with the frame
+    assert p1.flow_uv_derotated.dtype == np.float64 and p1.flow_mag.shape == (H, W)
+    with _lib.Context(W, H, 1) as c:
+        with pytest.raises(TypeError):
+            c.detect(ds1.get_flow_uv(1), np.zeros((2000, 2), np.uint32))
+    # the float32 loop derives the two attributes lazily
+    ds = SyntheticDataset(W, H, 3, use_farneback=False, dangle=(0.004, -0.002, 0.001))
+    p = Processor(RunConfig(logging.getLogger("t"), ds, "", False, False, False, True, False, False, "FLOW_FOE_CLUSTERING"))
+    p.run_detection()
+    exp = p.detector.derotate(0, 1, ds.get_flow_uv(1))
+    from mavflow import im_helpers
+    assert np.array_equal(p.flow_uv_derotated, exp) and np.array_equal(p.flow_mag, im_helpers.get_magnitude(exp))
+
+
+def test_pinned_pool_is_capped(mav):
+    """Idle page-locked result blocks are capped in total (least recently used sizes go first), not kept for ever per distinct size."""
+    from mavflow import _lib
+    pool = _lib._PinnedPool()
+    pool.CAP_BYTES = 3 << 20
+    with _lib.Context(64, 64, 1) as c:
+        for mb in (1, 2, 1, 2, 3, 1):
+            a = pool.empty(c, (mb << 20,), np.uint8)
+            a[0] = 1
+            del a
+            import gc
+            gc.collect()
+            assert pool.idle_bytes <= pool.CAP_BYTES, (mb, pool.idle_bytes)
+        assert sum(len(v) * k for k, v in pool.free.items()) == pool.idle_bytes
+        for lst in pool.free.values():                  # leave nothing page-locked behind
+            while lst:
+                c.lib.mav_host_free(None, lst.pop())
+
+
 def test_farneback_flow_provider_fills_the_reference_flow_seam(mav, tmp_path, fb_oracle):
     """Dataset.get_flow_uv (/root/reference/src/datasets/dataset.py:205-212) answered by Farneback on the GPU; the .flo files
     it leaves behind are readable through the reference's own layout."""
