@@ -340,6 +340,28 @@ def main():
         assert allrec[rank * B:(rank + 1) * B].tobytes() == res_last.tobytes(), "all-gathered records differ from the local ones"
     if rank == 0 and not args.no_verify:
         verification = verify_last_step(ctx, prev, nxt, samples, res_last, d_mf, d_md, sorted({0, B - 1}), args.levels)
+        # ... and EVERY pair of the timed step against the same batch re-run in the plain schedule (one stream, sweep-major, one group
+        # at a time: the form the parity tests check against the oracle): records, both masks and the whole flow must be identical
+        import zlib
+
+        def digest():
+            return (d_res.download(np.uint8, (B * rec,)).tobytes(), zlib.crc32(d_mf.download(np.uint8, (B * W * H,))),
+                    zlib.crc32(d_md.download(np.uint8, (B * W * H,))), [zlib.crc32(ctx.last_flow(b)) for b in range(B)])
+        timed = digest()
+        saved = {k: ctx.get_option(k) for k in ("pairs_in_flight", "bands")}
+        ctx.set_option("pairs_in_flight", 1)
+        ctx.set_option("bands", 1)
+        run_batch()
+        ctx.sync()
+        plain = digest()
+        for k, v in saved.items():
+            ctx.set_option(k, v)
+        same = [b for b in range(B) if timed[3][b] == plain[3][b]]
+        verification["all_pairs_equal_plain_schedule"] = bool(timed[:3] == plain[:3] and len(same) == B)
+        verification["pairs_with_identical_flow_in_plain_schedule"] = len(same)
+        if not verification["all_pairs_equal_plain_schedule"]:
+            differing = set(range(B)) - set(same)
+            verification["failed_pairs"] = sorted(set(verification["failed_pairs"]) | (differing if differing else {-1}))
 
     # ---- PCIe-inclusive rates (never `value`).  (1) naive: the two u8 frame stacks uploaded synchronously from pageable memory
     #      inside the loop; (2) pipelined: pinned memory, uploads on the context's copy stream into a second buffer set while
@@ -411,6 +433,7 @@ def main():
         ctx.profile_enable(2)
         run_batch()
         busy_ms = ctx.profile_busy("blur_iter", "blur_iter_coarse")
+        busy_all_ms = ctx.profile_busy(*prof.keys())        # time during which ANY kernel of the step was running (both streams)
         ctx.profile_enable(False)
         sum_ms = prof["blur_iter"][0] + prof.get("blur_iter_coarse", (0.0, 0))[0]
         launches = prof["blur_iter"][1] + prof.get("blur_iter_coarse", (0, 0))[1]
@@ -468,6 +491,10 @@ def main():
                     "alg_bytes_per_launch_avg": int(bytes_moved / max(launches, 1)),
                     "alg_bytes_per_launch_avg_survey_88B_model": int(bytes_survey / max(launches, 1)),
                     "kernel_share_of_step": round(ms / (1e3 * elapsed / args.steps), 3),
+                    "device_busy_ms": round(busy_all_ms, 3),
+                    "device_busy_note": "union of ALL kernel classes' intervals in the one-step pass with HIP events around runs of launches (no tracer: "
+                                        "under rocprofv3 the host side of the ~1 700 launches per step becomes the bottleneck and idle gaps appear "
+                                        "that the untraced run does not have); step time minus this = time in which nothing runs on the device",
                     "all_kernels_ms": {k: round(v[0], 3) for k, v in prof.items()}}
 
     # ---- the other BASELINE configurations one GPU can hold (never `value`; outside the headline's timed region) ----

@@ -86,6 +86,9 @@ int mav_device_count(void);       /* <= 0 when no GPU is visible */
  *                      ~2.6 Mpx, above that as many as keep a band's working set inside the Infinity Cache)
  *   "share_m"          one-stream schedule: all pairs of a group ping-pong M through the first slot's buffers (default 1)
  *   "share_frames"     0: treat a frame sequence (see mav_farneback) as independent pairs (default 1)
+ *   "small_batch"      default 1: a group whose finest-layer working set is at most 200 MB (one 1080p pair, two 720p pairs: a chain of
+ *                      launches that each fill a fraction of the chip) gets the layer images of its whole pyramid from ONE launch and
+ *                      all polynomial expansions from ONE launch instead of two launches per layer
  *   "strip"            width in tiles of the column strips of the XCD-aware tile order (0 = automatic)
  *   "phi_screen"       0: every pixel of the phi / threshold stage takes the exact path (default 1: float32 screen in front of it)
  *   "phi_yloop"        16-row blocks per workgroup of the phi kernel (0 = automatic)

@@ -9,6 +9,8 @@
 // The path is HBM/LDS-bound stencil work: no MFMA.
 #include "mavflow_internal.h"
 
+#include <algorithm>
+
 static __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -429,22 +431,19 @@ __global__ __launch_bounds__(256) void k_blur_resize_v(const float* __restrict__
 // pitch_w > 0: the tile's u8 source region (rows [ylo, yhi], the columns its 64 destination columns need) goes through LDS first
 // (stage_rows: ~7 coalesced dword loads per thread instead of ~70 single-byte loads) and the horizontal pass reads it from there;
 // pitch_w == 0 (regions too large for LDS): every thread reads its bytes from global memory.
-__global__ __launch_bounds__(256) void k_blur_resize_fused(const uint8_t* __restrict__ img, const uint8_t* __restrict__ img2, int split,
-                                                           size_t img_stride, int W, int H, int w, int h, BlurParams bp,
-                                                           float* __restrict__ out, size_t out_stride, int rows_cap, int pitch_w, int dword_ok,
-                                                           int dword_pad)
+// one 64 x FB_TH tile of one image: base = the u8 frame, out = the layer image of that frame
+static __device__ __forceinline__ void blur_fused_tile(const uint8_t* __restrict__ base, float* __restrict__ out, int W, int H, int w, int h,
+                                                       const BlurParams& bp, int rows_cap, int pitch_w, int dword_ok, int tile_x, int tile_y,
+                                                       float* __restrict__ hrows)
 {
-    extern __shared__ __attribute__((aligned(16))) float hrows[];       // [rows_cap][64] f32, then [rows_cap][pitch_w] dwords of u8
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // (Measured and not kept: a 1-D grid in tile_of_block's XCD-aware order, so that the 128-byte lines horizontally adjacent tiles
     // share are re-read from one XCD's L2 -- 72.0 vs 69.6 us per launch; workgroups that walk 4 - 8 tiles -- 104 vs 72 us.  PMC says
     // why: the kernel issues ~1000 VALU instructions per wave, index arithmetic and double-precision resize coordinates as much as
     // filter taps, so it is instruction-bound.  Hence: the tile's first / last source column come from lanes 0 / 63 of the wave's own
     // coordinates, and the 16 destination rows' source coordinates are evaluated once per wave, by lanes 0 - 15.)
-    const int tile_x = blockIdx.x, tile_y = blockIdx.y, img_z = blockIdx.z;
     const int dx0 = tile_x * 64;
     const int dx = dx0 + lane, dxc = min(dx, w - 1);
-    const uint8_t* base = image_of(img, img2, split, img_stride, img_z);
     const int r = bp.ksize >> 1;
     int s0; float f;
     resize_coord(dxc, W, w, bp.scale_x, &s0, &f);
@@ -486,9 +485,18 @@ __global__ __launch_bounds__(256) void k_blur_resize_fused(const uint8_t* __rest
         const int t0 = __builtin_amdgcn_readlane(row_s, j * 4 + wv);
         const float tf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(row_f), j * 4 + wv));
         const float v = blur_v1([&](int y) { return col[y * 64]; }, H, t0, tf, bp);
-        if (dx < w) out[(size_t)img_z * out_stride + (size_t)dy * w + dx] = v;
+        if (dx < w) out[(size_t)dy * w + dx] = v;
     }
 }
+__global__ __launch_bounds__(256) void k_blur_resize_fused(const uint8_t* __restrict__ img, const uint8_t* __restrict__ img2, int split,
+                                                           size_t img_stride, int W, int H, int w, int h, BlurParams bp,
+                                                           float* __restrict__ out, size_t out_stride, int rows_cap, int pitch_w, int dword_ok)
+{
+    extern __shared__ __attribute__((aligned(16))) float hrows[];       // [rows_cap][64] f32, then [rows_cap][pitch_w] dwords of u8
+    blur_fused_tile(image_of(img, img2, split, img_stride, blockIdx.z), out + (size_t)blockIdx.z * out_stride, W, H, w, h, bp, rows_cap, pitch_w,
+                    dword_ok, blockIdx.x, blockIdx.y, hrows);
+}
+
 static int fused_blur_rows(int H, int h, int ksize) { return (int)((FB_TH - 1) * ((double)H / h)) + (ksize | 1) + 4; }
 // dwords per staged source row: the columns 64 destination pixels need (63 scale + 1 + ksize), the 4-alignment slack and the word
 // blur_h4_stream reads ahead
@@ -501,14 +509,11 @@ bool blur_resize_is_fused(int W, int H, int w, int h, int ksize)
 // Layer 0 (scale 1, sigma 0 -> fixed kernel [1/4, 1/2, 1/4], BORDER_REFLECT_101): every product is exact in f32,
 // so this is bit-identical to OpenCV's row-then-column filter.  One thread = 4 consecutive pixels x 4 rows:
 // six aligned u32 row loads + the two neighbour bytes per row, float4 stores.
-__global__ __launch_bounds__(256) void k_blur3_u8(const uint8_t* __restrict__ img, const uint8_t* __restrict__ img2, int split,
-                                                  size_t img_stride, int W, int H, float* __restrict__ out, size_t out_stride)
+static __device__ __forceinline__ void blur3_block(const uint8_t* __restrict__ src, float* __restrict__ dst, int W, int H, int bx, int by)
 {
-    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-    const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 4;
+    const int x = (bx * 64 + (threadIdx.x & 63)) * 4;
+    const int y0 = (by * 4 + (threadIdx.x >> 6)) * 4;
     if (x >= W || y0 >= H) return;
-    const uint8_t* src = image_of(img, img2, split, img_stride, blockIdx.z);
-    float* dst = out + (size_t)blockIdx.z * out_stride;
     const int xl = x == 0 ? 1 : x - 1;                    // reflect101
     const int xr = x + 4 >= W ? W - 2 : x + 4;
     // all 18 loads of the thread first (six rows x {left byte, aligned dword, right byte}); the outputs below are computed
@@ -547,8 +552,65 @@ __global__ __launch_bounds__(256) void k_blur3_u8(const uint8_t* __restrict__ im
     }
 }
 
+// The layer images of SEVERAL layers in one launch (a small group's pyramid: launch_blur_multi): job 0.. = layers whose blur is the
+// 3x3 form (layer 0) or the fused form; workgroup b belongs to the last job whose first_block is <= b.
+__global__ __launch_bounds__(256) void k_blur_multi(const uint8_t* __restrict__ img, const uint8_t* __restrict__ img2, int split, size_t img_stride,
+                                                    int W, int H, int dword_ok, BlurJobs jobs)
+{
+    extern __shared__ __attribute__((aligned(16))) float hrows[];
+    int k = 0;
+    for (int i = 1; i < jobs.n; i++) k = (int)blockIdx.x >= jobs.j[i].first_block ? i : k;
+    const BlurJob J = jobs.j[k];
+    const int b = (int)blockIdx.x - J.first_block;
+    const int z = b / (J.gx * J.gy), rem = b - z * J.gx * J.gy;
+    const int by = rem / J.gx, bx = rem - by * J.gx;
+    const uint8_t* base = image_of(img, img2, split, img_stride, z);
+    float* out = J.out + (size_t)z * J.out_stride;
+    if (J.fused) blur_fused_tile(base, out, W, H, J.w, J.h, J.bp, J.rows_cap, J.pitch_w, dword_ok, bx, by, hrows);
+    else blur3_block(base, out, W, H, bx, by);
+}
+// Layer images of several layers of G frames in ONE launch.  jobs[i]: layer size, BlurParams, out / out_stride filled by the caller; a
+// layer qualifies when blur_multi_ok says so (3x3 form or fused form).  Grid bookkeeping and the LDS size are filled here.
+static bool blur3_fast_ok(const uint8_t* img, const uint8_t* img2, size_t img_stride, int W, int H, int w, int h, const BlurParams& bp,
+                          const float* out, size_t out_stride);
+bool blur_multi_ok(const uint8_t* img, const uint8_t* img2, size_t img_stride, int W, int H, int w, int h, BlurParams bp, const float* out,
+                   size_t out_stride)
+{
+    return blur3_fast_ok(img, img2 ? img2 : img, img_stride, W, H, w, h, bp, out, out_stride) || blur_resize_is_fused(W, H, w, h, bp.ksize);
+}
+void launch_blur_multi(hipStream_t st, const uint8_t* img, const uint8_t* img2, int split, size_t img_stride, int G, int W, int H, BlurJobs jobs)
+{
+    if (!img2) { img2 = img; split = G; }
+    const int dword_ok = (W % 4 == 0 && img_stride % 4 == 0 && ((uintptr_t)img & 3) == 0 && ((uintptr_t)img2 & 3) == 0) ? 1 : 0;
+    int blocks = 0;
+    size_t lds = 0;
+    for (int i = 0; i < jobs.n; i++) {
+        BlurJob& J = jobs.j[i];
+        J.fused = !(J.w == W && J.h == H);
+        if (J.fused) {
+            J.rows_cap = fused_blur_rows(H, J.h, J.bp.ksize);
+            const int pitch_w = staged_pitch_words(W, J.w, J.bp.ksize);
+            J.pitch_w = (size_t)J.rows_cap * (256 + 4 * pitch_w) <= 64 * 1024 ? pitch_w : 0;
+            J.gx = (J.w + 63) / 64; J.gy = (J.h + FB_TH - 1) / FB_TH;
+            lds = std::max(lds, (size_t)J.rows_cap * (256 + 4 * J.pitch_w));
+        } else {
+            J.rows_cap = J.pitch_w = 0;
+            J.gx = (W / 4 + 63) / 64; J.gy = ((H + 3) / 4 + 3) / 4;
+        }
+        J.first_block = blocks;
+        blocks += J.gx * J.gy * G;
+    }
+    hipLaunchKernelGGL(k_blur_multi, dim3(blocks), dim3(256), lds, st, img, img2, split, img_stride, W, H, dword_ok, jobs);
+}
+
 // G images: the first `split` from run img, the rest from run img2 (both with stride img_stride); split >= G: one run.
 // two_pass: force the separable two-pass form through the tmp scratch (the stage hook compares the two forms).
+__global__ __launch_bounds__(256) void k_blur3_u8(const uint8_t* __restrict__ img, const uint8_t* __restrict__ img2, int split,
+                                                  size_t img_stride, int W, int H, float* __restrict__ out, size_t out_stride)
+{
+    blur3_block(image_of(img, img2, split, img_stride, blockIdx.z), out + (size_t)blockIdx.z * out_stride, W, H, blockIdx.x, blockIdx.y);
+}
+
 static bool blur3_fast_ok(const uint8_t* img, const uint8_t* img2, size_t img_stride, int W, int H, int w, int h, const BlurParams& bp,
                           const float* out, size_t out_stride)
 {
@@ -577,7 +639,7 @@ void launch_blur_resize(hipStream_t st, const uint8_t* img, const uint8_t* img2,
         const int rows = fused_blur_rows(H, h, bp.ksize);
         const int pw = (size_t)rows * (256 + 4 * pitch_w) <= 64 * 1024 ? pitch_w : 0;       // both regions within 64 KB, or the direct form
         hipLaunchKernelGGL(k_blur_resize_fused, dim3((w + 63) / 64, (h + FB_TH - 1) / FB_TH, G), dim3(256), (size_t)rows * (256 + 4 * pw), st, img,
-                           img2, split, img_stride, W, H, w, h, bp, out, out_stride, rows, pw, dword_ok, 0);
+                           img2, split, img_stride, W, H, w, h, bp, out, out_stride, rows, pw, dword_ok);
         return;
     }
     int rows_blk = 16;
@@ -604,13 +666,11 @@ void launch_blur_resize(hipStream_t st, const uint8_t* img, const uint8_t* img2,
 // ------------------------------------------------------------------------------------------------------------
 #define PX 64
 #define PY 16
+// one 64 x 16 tile of one image: src / dst = the image's layer plane and its five expansion planes
 template <int N_T>
-__global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ I, size_t I_stride, int w, int h, PolyCoef pc, TileMap tm,
-                                                 float* __restrict__ R, size_t R_stride)
+static __device__ __forceinline__ void polyexp_tile(const float* __restrict__ src, float* __restrict__ dst, int w, int h, const PolyCoef& pc,
+                                                    int tile_x, int tile_y, float* __restrict__ smem)
 {
-    int img_s, tile_x, tile_y;
-    if (!tile_of_block(tm, &img_s, &tile_x, &tile_y)) return;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n = N_T > 0 ? N_T : pc.n;
     const int EX = PX + 2 * n, EY = PY + 2 * n;
     float* tile = smem;
@@ -619,7 +679,6 @@ __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ I, si
     float* v2 = v1 + PY * EX;
     const int tid = threadIdx.x;
     const int x0 = tile_x * PX, y0 = tile_y * PY;
-    const float* src = I + (size_t)img_s * I_stride;
 
     if constexpr (N_T > 0) {
         // all of a thread's loads are issued before the first one is consumed (a load -> LDS-store loop would serialise
@@ -662,7 +721,6 @@ __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ I, si
     }
     __syncthreads();
     const size_t npx = (size_t)w * h;
-    float* dst = R + (size_t)img_s * R_stride;
     for (int i = tid; i < PY * PX; i += 256) {
         const int ly = i >> 6, lx = i & 63;
         const int gx = x0 + lx, gy = y0 + ly;
@@ -691,6 +749,48 @@ __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ I, si
     }
 }
 
+template <int N_T>
+__global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ I, size_t I_stride, int w, int h, PolyCoef pc, TileMap tm,
+                                                 float* __restrict__ R, size_t R_stride)
+{
+    int img_s, tile_x, tile_y;
+    if (!tile_of_block(tm, &img_s, &tile_x, &tile_y)) return;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    polyexp_tile<N_T>(I + (size_t)img_s * I_stride, R + (size_t)img_s * R_stride, w, h, pc, tile_x, tile_y, smem);
+}
+
+// The expansions of SEVERAL layers in one launch (a small group's whole pyramid: launch_polyexp_multi): workgroup b belongs to the
+// last job whose first_block is <= b and takes that job's tile b - first_block (plain row-major order, image by image).
+template <int N_T>
+__global__ __launch_bounds__(256) void k_polyexp_multi(PolyJobs jobs, PolyCoef pc)
+{
+    int k = 0;
+    for (int i = 1; i < jobs.n; i++) k = (int)blockIdx.x >= jobs.j[i].first_block ? i : k;
+    const PolyJob J = jobs.j[k];
+    const int tile = (int)blockIdx.x - J.first_block;
+    const int img_s = tile / J.per_img, rem = tile - img_s * J.per_img;
+    const int tile_y = rem / J.tiles_x, tile_x = rem - tile_y * J.tiles_x;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    polyexp_tile<N_T>(J.I + (size_t)img_s * J.I_stride, J.R + (size_t)img_s * J.R_stride, J.w, J.h, pc, tile_x, tile_y, smem);
+}
+// jobs[i]: G images of a (w x h) layer at I (slot stride I_stride) -> R (slot stride R_stride); first_block / tiles_x / per_img are filled here
+void launch_polyexp_multi(hipStream_t st, PolyJobs jobs, int G, const PolyCoef& pc)
+{
+    const int n = pc.n;
+    const size_t lds = sizeof(float) * ((size_t)(PX + 2 * n) * (PY + 2 * n) + 3 * (size_t)PY * (PX + 2 * n));
+    int blocks = 0;
+    for (int i = 0; i < jobs.n; i++) {
+        PolyJob& J = jobs.j[i];
+        J.tiles_x = (J.w + PX - 1) / PX;
+        J.per_img = J.tiles_x * ((J.h + PY - 1) / PY);
+        J.first_block = blocks;
+        blocks += J.per_img * G;
+    }
+    if (n == 8) hipLaunchKernelGGL(k_polyexp_multi<8>, dim3(blocks), dim3(256), lds, st, jobs, pc);
+    else if (n == 7) hipLaunchKernelGGL(k_polyexp_multi<7>, dim3(blocks), dim3(256), lds, st, jobs, pc);
+    else if (n == 5) hipLaunchKernelGGL(k_polyexp_multi<5>, dim3(blocks), dim3(256), lds, st, jobs, pc);
+    else hipLaunchKernelGGL(k_polyexp_multi<0>, dim3(blocks), dim3(256), lds, st, jobs, pc);
+}
 
 void launch_polyexp(hipStream_t st, const float* I, size_t I_stride, int G, int w, int h, const PolyCoef& pc, float* R,
                     size_t R_stride)

@@ -202,7 +202,15 @@ struct mav_ctx {
         // R = R0 | R1 in ONE allocation (R1 = R0 + 5 n0 group): the expansions of the two frames of every pair.  For a frame SEQUENCE
         // (next = prev + one frame) the group's g + 1 frames are expanded once into slots 0 .. g and pair s reads slots s and s + 1.
         float *I = nullptr, *R = nullptr, *Ma = nullptr, *Mb = nullptr, *fc[2] = {nullptr, nullptr};
+        // small groups (flow_group): the coarse layers' images / expansions, every layer in a region of its own (layer k: c_off[k]
+        // floats per frame in, c_stride[k] floats per frame), so that the whole pyramid can be blurred and expanded in two launches
+        float *Ic = nullptr, *Rc = nullptr;
     } ws;
+    std::vector<size_t> c_off, c_stride;      // per layer (index 0 unused); c_total = sum of the strides
+    size_t c_total = 0;
+    int small_g = 0;                          // pairs the Ic / Rc buffers were sized for (0: none)
+    bool small_batch = true;                  // option "small_batch"
+    int small_batch_mb = 200;                 // option "small_batch_mb": ... for groups of at most this much finest-layer sweep working set
     int bands = 1;                   // option "bands": the finest layer's sweeps in band-major order over this many skewed bands
     // option "pairs_in_flight" (1 or 2): the finest layer's per-pair work (initial M + sweeps) of a group alternates between the
     // compute stream and pair_stream, every pair band-major over bands of at most pif_band_mb of working set (layer_sweeps)
@@ -300,8 +308,12 @@ static int alloc_group(mav_ctx* c, int group)
     const size_t g = (size_t)group, nc = 2 * (c->n1 ? c->n1 : 1);
     // I / I2 hold the 2 g frames of a group (prev and next in one launch; a frame sequence of g pairs has g + 1 <= 2 g frames);
     // Htmp holds g + 1 (the two-pass blur never runs over more frames per launch)
-    enum { NB = 7 };
-    const size_t elems[NB] = {c->n0 * 2 * g, 10 * c->n0 * g, 5 * c->n0 * g, 5 * c->n0 * g, nc * g, nc * g, c->htmp_stride * (g + 1)};
+    enum { NB = 9 };
+    // Ic / Rc: for the largest group the small-group schedule can take (is_small_group), 2 g frames of every coarse layer
+    size_t sg = c->c_total ? ((size_t)c->small_batch_mb << 20) / (c->n0 * 80) : 0;
+    if (sg > g) sg = g;
+    const size_t elems[NB] = {c->n0 * 2 * g, 10 * c->n0 * g, 5 * c->n0 * g, 5 * c->n0 * g, nc * g, nc * g, c->htmp_stride * (g + 1),
+                              sg ? 2 * sg * c->c_total : 1, sg ? 10 * sg * c->c_total : 1};
     float* fresh[NB] = {nullptr};
     for (int i = 0; i < NB; i++) {
         const hipError_t e = hipMalloc(&fresh[i], sizeof(float) * elems[i]);
@@ -313,9 +325,10 @@ static int alloc_group(mav_ctx* c, int group)
         }
     }
     mav_ctx::WorkSet& w = c->ws;
-    float** bufs[NB] = {&w.I, &w.R, &w.Ma, &w.Mb, &w.fc[0], &w.fc[1], &w.Htmp};
+    float** bufs[NB] = {&w.I, &w.R, &w.Ma, &w.Mb, &w.fc[0], &w.fc[1], &w.Htmp, &w.Ic, &w.Rc};
     for (int i = 0; i < NB; i++) { if (*bufs[i]) hipFree(*bufs[i]); *bufs[i] = fresh[i]; }
     c->group = group;
+    c->small_g = (int)sg;
     return MAV_OK;
 }
 
@@ -334,7 +347,7 @@ extern "C" int mav_destroy(mav_ctx* c)
     for (auto& l : c->layers) free_layer(l);
     {
         mav_ctx::WorkSet& w = c->ws;
-        void* wb[] = {w.I, w.R, w.Ma, w.Mb, w.fc[0], w.fc[1], w.Htmp};
+        void* wb[] = {w.I, w.R, w.Ma, w.Mb, w.fc[0], w.fc[1], w.Htmp, w.Ic, w.Rc};
         for (void* b : wb) if (b) hipFree(b);
     }
     void* bufs[] = {c->flow_ws, c->foe_sc.cand, c->foe_sc.count, c->foe_sc.best_key, c->foe_sc.done, c->foe_dev, c->box_acc, c->u64_scratch,
@@ -413,6 +426,12 @@ extern "C" int mav_create(mav_ctx** out, int device, int W, int H, int max_batch
     }
     c->n0 = (size_t)W * H;
     c->n1 = levels >= 1 ? (size_t)c->layers[1].w * c->layers[1].h : 0;
+    c->c_off.assign(levels + 1, 0); c->c_stride.assign(levels + 1, 0);
+    for (int k = 1; k <= levels; k++) {                 // slot strides rounded up to 64 floats: every slot stays 256-byte aligned
+        c->c_stride[k] = ((size_t)c->layers[k].w * c->layers[k].h + 63) & ~(size_t)63;
+        c->c_off[k] = c->c_total;
+        c->c_total += c->c_stride[k];
+    }
     c->htmp_stride = (size_t)H * W;                    // any layer (even layer 0 when its fast form does not apply) fits
     // group: pairs per launch for everything but the finest layer's sweeps (see flow_group).
     // (1080p, 64 pairs: 27.0 - 27.5 ms with groups of 16 or 32, 27.8 - 28.1 with 8, 28.4 with 4 -- the batched blur / expansion
@@ -449,7 +468,7 @@ struct OptionDesc { const char* name; long lo, hi; };
 static const OptionDesc kOptions[] = {
     {"group", 1, 1 << 20}, {"group_fine", 0, 1 << 20}, {"bands", 1, 8}, {"pairs_in_flight", 1, 2}, {"band_mb", 8, 1 << 20},
     {"coarse_cache_mb", 0, 1 << 20}, {"coarse_half", 0, 1 << 20}, {"share_m", 0, 1}, {"share_frames", 0, 1}, {"strip", 0, 1 << 20},
-    {"phi_screen", 0, 1}, {"phi_yloop", 0, 1 << 20},
+    {"phi_screen", 0, 1}, {"phi_yloop", 0, 1 << 20}, {"small_batch", 0, 1},
 };
 static long* option_slot(mav_ctx* c, const char* name, long* tmp)
 {
@@ -458,6 +477,7 @@ static long* option_slot(mav_ctx* c, const char* name, long* tmp)
         {"group", c->group}, {"group_fine", c->group_fine}, {"bands", c->bands}, {"pairs_in_flight", c->pairs_in_flight},
         {"band_mb", c->pif_band_mb}, {"coarse_cache_mb", c->coarse_cache_mb}, {"coarse_half", c->coarse_half}, {"share_m", c->share_m},
         {"share_frames", c->share_frames}, {"strip", c->strip}, {"phi_screen", c->phi_screen}, {"phi_yloop", c->phi_yloop},
+        {"small_batch", c->small_batch},
     };
     for (auto& e : cur) if (!strcmp(e.n, name)) { *tmp = e.v; return tmp; }
     return nullptr;
@@ -495,6 +515,7 @@ extern "C" int mav_set_option(mav_ctx* c, const char* name, long value)
     else if (!strcmp(name, "strip")) c->strip = v;
     else if (!strcmp(name, "phi_screen")) c->phi_screen = v != 0;
     else if (!strcmp(name, "phi_yloop")) c->phi_yloop = v;
+    else if (!strcmp(name, "small_batch")) c->small_batch = v != 0;
     return MAV_OK;
 }
 
@@ -785,8 +806,8 @@ static SweepPlan plan_sweeps(const mav_ctx* c, int k, int g, bool bands_ok)
 // above have written into Ma (their odd sweeps end one whole tile row higher); the rows two neighbouring bands both need are
 // simply built twice, to the same values.
 struct BandUpdate { const float* flow_prev; size_t fc_stride; int pw, ph; float mul; };
-static void sweeps_band_major(mav_ctx* c, hipStream_t st, int kid, float* Ma, float* Mb, const float* r0, const float* r1, int gs, int lw,
-                              int lh, int T, int J, float* fo, size_t fstride, const BandUpdate* upd = nullptr)
+static void sweeps_band_major(mav_ctx* c, hipStream_t st, int kid, float* Ma, float* Mb, const float* r0, const float* r1, size_t rs, int gs,
+                              int lw, int lh, int T, int J, float* fo, size_t fstride, const BandUpdate* upd = nullptr)
 {
     const size_t n0 = c->n0;
     const int I = c->fb.iterations;
@@ -794,7 +815,7 @@ static void sweeps_band_major(mav_ctx* c, hipStream_t st, int kid, float* Ma, fl
         const int a0 = (int)((long long)T * j / J), a1 = (int)((long long)T * (j + 1) / J);
         if (upd) {
             ProfScope ps(c, K_UPDATE, st);
-            launch_update_matrices(st, r0, r1, 5 * n0, upd->flow_prev, upd->fc_stride, upd->pw, upd->ph, upd->mul, gs, lw, lh, Ma, 5 * n0,
+            launch_update_matrices(st, r0, r1, rs, upd->flow_prev, upd->fc_stride, upd->pw, upd->ph, upd->mul, gs, lw, lh, Ma, 5 * n0,
                                    j == 0 ? 0 : a0 * 16 - 8, j == J - 1 ? lh : a1 * 16 + 8);
         }
         for (int it = 0; it < I; it++) {
@@ -803,36 +824,36 @@ static void sweeps_band_major(mav_ctx* c, hipStream_t st, int kid, float* Ma, fl
             if (ty0 < 0) ty0 = 0;
             if (ty1 <= ty0) continue;
             ProfScope ps(c, kid, st);
-            launch_blur_iter(st, (it & 1) ? Mb : Ma, (it & 1) ? Ma : Mb, 5 * n0, r0, r1, 5 * n0, gs, lw, lh, c->fb.winsize, update, !update, fo,
+            launch_blur_iter(st, (it & 1) ? Mb : Ma, (it & 1) ? Ma : Mb, 5 * n0, r0, r1, rs, gs, lw, lh, c->fb.winsize, update, !update, fo,
                              fstride, ty0, ty1, c->strip);
         }
     }
 }
 
 // initial M + the `iterations` sweeps of gs pairs, sweep-major, on stream ss
-static void sweeps_plain(mav_ctx* c, hipStream_t ss, int kid, float* Min, float* Mout, const float* r0, const float* r1, int gs, const Layer& l,
-                         float* fo, size_t fstride)
+static void sweeps_plain(mav_ctx* c, hipStream_t ss, int kid, float* Min, float* Mout, const float* r0, const float* r1, size_t rs, int gs,
+                         const Layer& l, float* fo, size_t fstride)
 {
     const size_t n0 = c->n0;
     for (int it = 0; it < c->fb.iterations; it++) {
         const int update = it < c->fb.iterations - 1;
         { ProfScope ps(c, kid, ss);
-          launch_blur_iter(ss, Min, Mout, 5 * n0, r0, r1, 5 * n0, gs, l.w, l.h, c->fb.winsize, update, !update, fo, fstride, 0, -1, c->strip); }
+          launch_blur_iter(ss, Min, Mout, 5 * n0, r0, r1, rs, gs, l.w, l.h, c->fb.winsize, update, !update, fo, fstride, 0, -1, c->strip); }
         if (update) { float* t = Min; Min = Mout; Mout = t; }
     }
 }
 
-// Initial M and the `iterations` sweeps of layer k for g pairs whose expansions lie at r0 / r1 (slot stride 5 n0), starting on
+// Initial M and the `iterations` sweeps of layer k for g pairs whose expansions lie at r0 / r1 (slot stride rs), starting on
 // stream st.  flow_prev = the coarser layer's flow (pw x ph, nullptr at the top layer); the layer's flow goes to fdst (slot stride
 // fstride).  On return everything has been joined back into st.
-static int layer_sweeps(mav_ctx* c, hipStream_t st, int k, int g, const float* r0g, const float* r1g, const float* flow_prev, size_t fc_stride,
-                        int pw, int ph, float* fdst, size_t fstride)
+static int layer_sweeps(mav_ctx* c, hipStream_t st, int k, int g, const float* r0g, const float* r1g, size_t rs, const float* flow_prev,
+                        size_t fc_stride, int pw, int ph, float* fdst, size_t fstride)
 {
     mav_ctx::WorkSet& w = c->ws;
     const size_t n0 = c->n0;
     const Layer& l = c->layers[k];
     const float mul = (float)(1. / c->fb.pyr_scale);
-    const bool bands_ok = blur_iter_bands_ok(l.w, c->fb.winsize, 5 * n0, 5 * n0, fstride, w.Ma, w.Mb, r0g, r1g, fdst);
+    const bool bands_ok = blur_iter_bands_ok(l.w, c->fb.winsize, 5 * n0, rs, fstride, w.Ma, w.Mb, r0g, r1g, fdst);
     const SweepPlan p = plan_sweeps(c, k, g, bands_ok);
     const int kid = k == 0 ? K_ITER : K_ITER_COARSE;
     const int T = blur_iter_tile_rows(l.h);
@@ -842,16 +863,16 @@ static int layer_sweeps(mav_ctx* c, hipStream_t st, int k, int g, const float* r
         for (int s0 = 0; s0 < g; s0++) {
             const hipStream_t ss = (s0 & 1) ? c->pair_stream : st;
             float *Min = w.Ma + (size_t)(s0 & 1) * 5 * n0, *Mout = w.Mb + (size_t)(s0 & 1) * 5 * n0;
-            const float *r0 = r0g + (size_t)s0 * 5 * n0, *r1 = r1g + (size_t)s0 * 5 * n0;
+            const float *r0 = r0g + (size_t)s0 * rs, *r1 = r1g + (size_t)s0 * rs;
             float* fo = fdst + (size_t)s0 * fstride;
             const BandUpdate bu{flow_prev ? flow_prev + (size_t)s0 * fc_stride : nullptr, fc_stride, pw, ph, mul};
             if (p.J > 1) {
-                sweeps_band_major(c, ss, K_ITER, Min, Mout, r0, r1, 1, l.w, l.h, T, p.J, fo, fstride, &bu);
+                sweeps_band_major(c, ss, K_ITER, Min, Mout, r0, r1, rs, 1, l.w, l.h, T, p.J, fo, fstride, &bu);
                 continue;
             }
             { ProfScope ps(c, K_UPDATE, ss);
-              launch_update_matrices(ss, r0, r1, 5 * n0, bu.flow_prev, fc_stride, pw, ph, mul, 1, l.w, l.h, Min, 5 * n0); }
-            sweeps_plain(c, ss, K_ITER, Min, Mout, r0, r1, 1, l, fo, fstride);
+              launch_update_matrices(ss, r0, r1, rs, bu.flow_prev, fc_stride, pw, ph, mul, 1, l.w, l.h, Min, 5 * n0); }
+            sweeps_plain(c, ss, K_ITER, Min, Mout, r0, r1, rs, 1, l, fo, fstride);
         }
         prof_close_stream(c, c->pair_stream); prof_close_stream(c, st);
         HIPCHK(hipEventRecord(c->pif_join, c->pair_stream));
@@ -866,11 +887,11 @@ static int layer_sweeps(mav_ctx* c, hipStream_t st, int k, int g, const float* r
             const int gs = g - s0 < p.half ? g - s0 : p.half;
             const hipStream_t ss = (idx & 1) ? c->pair_stream : st;
             const size_t m_off = (size_t)(idx & 1) * p.half * 5 * n0;
-            const float *r0 = r0g + (size_t)s0 * 5 * n0, *r1 = r1g + (size_t)s0 * 5 * n0;
+            const float *r0 = r0g + (size_t)s0 * rs, *r1 = r1g + (size_t)s0 * rs;
             { ProfScope ps(c, K_UPDATE, ss);
-              launch_update_matrices(ss, r0, r1, 5 * n0, flow_prev ? flow_prev + (size_t)s0 * fc_stride : nullptr, fc_stride, pw, ph, mul, gs, l.w, l.h,
+              launch_update_matrices(ss, r0, r1, rs, flow_prev ? flow_prev + (size_t)s0 * fc_stride : nullptr, fc_stride, pw, ph, mul, gs, l.w, l.h,
                                      w.Ma + m_off, 5 * n0); }
-            sweeps_plain(c, ss, K_ITER_COARSE, w.Ma + m_off, w.Mb + m_off, r0, r1, gs, l, fdst + (size_t)s0 * fstride, fstride);
+            sweeps_plain(c, ss, K_ITER_COARSE, w.Ma + m_off, w.Mb + m_off, r0, r1, rs, gs, l, fdst + (size_t)s0 * fstride, fstride);
         }
         prof_close_stream(c, c->pair_stream); prof_close_stream(c, st);
         HIPCHK(hipEventRecord(c->pif_join, c->pair_stream));
@@ -879,7 +900,7 @@ static int layer_sweeps(mav_ctx* c, hipStream_t st, int k, int g, const float* r
     }
     if (!p.m_per_sub) {
         ProfScope ps(c, K_UPDATE, st);
-        launch_update_matrices(st, r0g, r1g, 5 * n0, flow_prev, fc_stride, pw, ph, mul, g, l.w, l.h, w.Ma, 5 * n0);
+        launch_update_matrices(st, r0g, r1g, rs, flow_prev, fc_stride, pw, ph, mul, g, l.w, l.h, w.Ma, 5 * n0);
     }
     // Sub-groups are swept one after the other on one stream, so they all ping-pong M through the SAME two buffers (the first
     // sub-group's slots; option "share_m"): the M lines then stay hot in the Infinity Cache from pair to pair instead of leaving a
@@ -887,15 +908,15 @@ static int layer_sweeps(mav_ctx* c, hipStream_t st, int k, int g, const float* r
     for (int s0 = 0; s0 < g; s0 += p.sub) {
         const int gs = g - s0 < p.sub ? g - s0 : p.sub;
         const size_t m_off = (p.m_per_sub && c->share_m) ? 0 : (size_t)s0 * 5 * n0;
-        const float *r0 = r0g + (size_t)s0 * 5 * n0, *r1 = r1g + (size_t)s0 * 5 * n0;
+        const float *r0 = r0g + (size_t)s0 * rs, *r1 = r1g + (size_t)s0 * rs;
         if (p.m_per_sub) {
             ProfScope ps(c, K_UPDATE, st);
-            launch_update_matrices(st, r0, r1, 5 * n0, flow_prev ? flow_prev + (size_t)s0 * fc_stride : nullptr, fc_stride, pw, ph, mul, gs, l.w,
+            launch_update_matrices(st, r0, r1, rs, flow_prev ? flow_prev + (size_t)s0 * fc_stride : nullptr, fc_stride, pw, ph, mul, gs, l.w,
                                    l.h, w.Ma + m_off, 5 * n0);
         }
         float* fo = fdst + (size_t)s0 * fstride;
-        if (p.J > 1 && gs == 1) sweeps_band_major(c, st, K_ITER, w.Ma + m_off, w.Mb + m_off, r0, r1, gs, l.w, l.h, T, p.J, fo, fstride);
-        else sweeps_plain(c, st, kid, w.Ma + m_off, w.Mb + m_off, r0, r1, gs, l, fo, fstride);
+        if (p.J > 1 && gs == 1) sweeps_band_major(c, st, K_ITER, w.Ma + m_off, w.Mb + m_off, r0, r1, rs, gs, l.w, l.h, T, p.J, fo, fstride);
+        else sweeps_plain(c, st, kid, w.Ma + m_off, w.Mb + m_off, r0, r1, rs, gs, l, fo, fstride);
     }
     return MAV_OK;
 }
@@ -941,24 +962,72 @@ static void layer_expansions(mav_ctx* c, hipStream_t st, int k, const uint8_t* p
     }
 }
 
+// does a group of g pairs take the small-group schedule?
+static bool is_small_group(const mav_ctx* c, int g)
+{
+    return c->small_batch && c->layers.size() > 1 && (int)c->layers.size() <= MAV_MAX_JOBS && g <= c->small_g &&
+           (size_t)g * c->n0 * 80 <= ((size_t)c->small_batch_mb << 20);
+}
+
 // One group of g pairs: every coarse layer completely (top layer first: images, expansions, initial M, sweeps), then the finest layer.
-// (Measured for groups of ONE pair, where the coarse layers are a chain of launches that each fill a fraction of the chip, and not
-// kept: the finest layer's images and expansions on a side stream underneath that chain.  Each of the two event operations the fork
-// and the join put on the compute stream costs ~6 us there, and the overlapped kernels slow the chain's own: 0.320 vs 0.306 ms per
-// 1280x720 pair, profiles/r03/c2_side_stream.txt.  For big groups the overlap loses too: the coarse layers' sweeps are cache-bound
-// and a concurrent HBM stream takes its share, profiles/r02/ab_overlap_fine_prep_with_coarse_sweeps.log.)
+// SMALL GROUPS (is_small_group: one 1080p pair, two 720p pairs ...; BASELINE config 2) are a chain of ~30 dependent launches that
+// each fill a fraction of the chip, ~4.5 us of boundary apiece.  For them the whole pyramid's layer images come from ONE launch and
+// all expansions from ONE launch (k_blur_multi / k_polyexp_multi: the workgroups of several layers in one grid, every layer into a
+// region of its own in Ic / Rc), instead of two launches per layer: the small layers ride along with the finest one.  Same tile
+// functions on the same data: bit-identical flow (tests/test_gpu_flow.py).
+// (Measured for such groups and not kept: the finest layer's images and expansions on a side stream underneath the coarse chain --
+// every event record / wait costs ~6 us on the compute stream and the overlapped kernels slow the chain's own: 0.320 vs 0.306 ms per
+// 1280x720 pair, profiles/r03/c2_side_stream.txt; all sweeps of a layer in one launch of resident workgroups that hand M' over through
+// flags -- a cross-CU hand-off costs what the kernel boundary costs: 0.419 vs 0.305 ms, profiles/r03/c2_resident_sweeps.txt.  For big
+// groups overlapping the finest layer's preparation with the coarse sweeps loses too: profiles/r02/ab_overlap_fine_prep_with_coarse_sweeps.log.)
 static int flow_group(mav_ctx* c, const uint8_t* prev, const uint8_t* next, int g, bool seq, float* flow_out)
 {
     mav_ctx::WorkSet& w = c->ws;
     const hipStream_t st = c->stream;
     const int L = (int)c->layers.size();
-    const size_t fc_stride = 2 * (c->n1 ? c->n1 : 1);
-    const float *r0 = nullptr, *r1 = nullptr;
+    const size_t n0 = c->n0, fc_stride = 2 * (c->n1 ? c->n1 : 1);
     const float* flow_prev = nullptr;
     int pw = 0, ph = 0;
+    if (is_small_group(c, g)) {
+        const int F = seq ? g + 1 : 2 * g;                                // frames: one run of g + 1, or the prev run and the next run
+        const uint8_t* img2 = seq ? nullptr : next;
+        auto Ik = [&](int k) { return k ? w.Ic + (size_t)F * c->c_off[k] : w.I; };
+        auto Rk = [&](int k) { return k ? w.Rc + 5 * (size_t)F * c->c_off[k] : w.R; };
+        auto sk = [&](int k) { return k ? c->c_stride[k] : n0; };
+        BlurJobs bj{0, 0, {}};
+        PolyJobs pj{0, 0, {}};
+        for (int k = 0; k < L; k++) {
+            const Layer& l = c->layers[k];
+            if (blur_multi_ok(prev, img2, n0, c->W, c->H, l.w, l.h, blur_of(c, l), Ik(k), sk(k))) {
+                BlurJob& J = bj.j[bj.n++];
+                J.out = Ik(k); J.out_stride = sk(k); J.bp = blur_of(c, l); J.w = l.w; J.h = l.h;
+            } else {                                                      // a long Gaussian (or an unaligned finest layer): launches of its own;
+                ProfScope ps(c, K_BLUR_RESIZE, st);                       // the two-pass scratch holds g + 1 frames
+                if (F <= g + 1)
+                    launch_blur_resize(st, prev, img2, g, n0, F, c->W, c->H, l.w, l.h, blur_of(c, l), w.Htmp, c->htmp_stride, Ik(k), sk(k));
+                else {
+                    launch_blur_resize(st, prev, nullptr, 0, n0, g, c->W, c->H, l.w, l.h, blur_of(c, l), w.Htmp, c->htmp_stride, Ik(k), sk(k));
+                    launch_blur_resize(st, next, nullptr, 0, n0, g, c->W, c->H, l.w, l.h, blur_of(c, l), w.Htmp, c->htmp_stride,
+                                       Ik(k) + (size_t)g * sk(k), sk(k));
+                }
+            }
+            PolyJob& P = pj.j[pj.n++];
+            P.I = Ik(k); P.R = Rk(k); P.I_stride = sk(k); P.R_stride = 5 * sk(k); P.w = l.w; P.h = l.h;
+        }
+        if (bj.n) { ProfScope ps(c, K_BLUR_RESIZE, st); launch_blur_multi(st, prev, img2, g, n0, F, c->W, c->H, bj); }
+        { ProfScope ps(c, K_POLYEXP, st); launch_polyexp_multi(st, pj, F, c->pc); }
+        for (int k = L - 1; k >= 0; k--) {
+            const size_t rs = 5 * sk(k);
+            const float *r0 = Rk(k), *r1 = Rk(k) + (seq ? rs : rs * (size_t)g);
+            CHK(layer_sweeps(c, st, k, g, r0, r1, rs, flow_prev, fc_stride, pw, ph, k ? w.fc[k & 1] : flow_out, k ? fc_stride : 2 * n0));
+            flow_prev = w.fc[k & 1]; pw = c->layers[k].w; ph = c->layers[k].h;
+        }
+        return MAV_OK;
+    }
+    const float *r0 = nullptr, *r1 = nullptr;
     for (int k = L - 1; k >= 0; k--) {
         layer_expansions(c, st, k, prev, next, g, seq, w.I, w.R, &r0, &r1);
-        CHK(layer_sweeps(c, st, k, g, r0, r1, flow_prev, fc_stride, pw, ph, k ? w.fc[k & 1] : flow_out, k ? fc_stride : 2 * c->n0));
+        CHK(layer_sweeps(c, st, k, g, r0, r1, 5 * n0, flow_prev, fc_stride, pw, ph, k ? w.fc[k & 1] : flow_out, k ? fc_stride : 2 * n0));
         flow_prev = w.fc[k & 1]; pw = c->layers[k].w; ph = c->layers[k].h;
     }
     return MAV_OK;
@@ -999,7 +1068,7 @@ extern "C" int mav_schedule_info(mav_ctx* c, int batch, char* buf, size_t cap)
         o += t;
     }
     const int g = batch < c->group ? batch : c->group;
-    snprintf(t, sizeof(t), "\"pairs_per_group\": %d, \"layers\": [", g);
+    snprintf(t, sizeof(t), "\"pairs_per_group\": %d, \"pyramid_in_two_launches\": %s, \"layers\": [", g, is_small_group(c, g) ? "true" : "false");
     o += t;
     static const char* const mode_names[] = {"one stream", "two pairs in flight, band-major", "two sub-groups in flight"};
     for (int k = 0; k < (int)c->layers.size(); k++) {

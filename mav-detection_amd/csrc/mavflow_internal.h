@@ -36,6 +36,13 @@ struct DerotParams {  // one pair; Detector.derotate
     int mode;                   // MAV_PAIR_*
 };
 
+// Several layers in one launch (a small group's whole pyramid): job tables passed by value in the kernel arguments.
+#define MAV_MAX_JOBS 6
+struct PolyJob { const float* I; float* R; size_t I_stride, R_stride; int w, h, tiles_x, per_img, first_block, pad; };
+struct PolyJobs { int n, pad; PolyJob j[MAV_MAX_JOBS]; };
+struct BlurJob { float* out; size_t out_stride; BlurParams bp; int w, h, fused, gx, gy, first_block, rows_cap, pitch_w; };
+struct BlurJobs { int n, pad; BlurJob j[MAV_MAX_JOBS]; };
+
 // ---- flow kernels (kernels_flow.hip) ----------------------------------------------------------------------
 // All take G slots; slot s reads/writes base + s*stride (strides in elements).
 // G images from two runs: the first `split` from img, the rest from img2 (same stride); img2 == nullptr: one run.  Layers with a
@@ -48,6 +55,12 @@ bool blur_resize_needs_tmp(const uint8_t* img, const uint8_t* img2, size_t img_s
                            const float* out, size_t out_stride);
 void launch_polyexp(hipStream_t st, const float* I, size_t I_stride, int G, int w, int h, const PolyCoef& pc, float* R,
                     size_t R_stride);
+// jobs.j[i]: I, R, I_stride, R_stride, w, h filled by the caller; G images per job
+void launch_polyexp_multi(hipStream_t st, PolyJobs jobs, int G, const PolyCoef& pc);
+// jobs.j[i]: out, out_stride, bp, w, h filled by the caller, for layers blur_multi_ok accepts
+bool blur_multi_ok(const uint8_t* img, const uint8_t* img2, size_t img_stride, int W, int H, int w, int h, BlurParams bp, const float* out,
+                   size_t out_stride);
+void launch_blur_multi(hipStream_t st, const uint8_t* img, const uint8_t* img2, int split, size_t img_stride, int G, int W, int H, BlurJobs jobs);
 // flow_prev == nullptr: zero initial flow. Otherwise flow = resize(prev (ph x pw x 2))*mul, evaluated inline.
 void launch_update_matrices(hipStream_t st, const float* R0, const float* R1, size_t R_stride, const float* flow_prev,
                             size_t fp_stride, int pw, int ph, float mul, int G, int w, int h, float* M, size_t M_stride,

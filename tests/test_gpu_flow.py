@@ -304,7 +304,19 @@ def test_small_groups_give_the_same_results_as_big_ones(mav, size, batch):
     prev, nxt = synth.make_batch(W, H, batch, distinct=min(batch, 4))
     smp = np.stack([synth.foe_samples(W, H, b) for b in range(batch)])
     with _lib.Context(W, H, max(batch, 4)) as c:
+        # small groups also get their whole pyramid from two launches (option "small_batch"): the reference is the per-layer form
+        c.set_option("small_batch", 0)
+        assert not c.schedule_info(batch)["pyramid_in_two_launches"]
         ref = c.process_batch(prev, nxt, smp)
+        c.set_option("small_batch", 1)
+        assert c.schedule_info(1)["pyramid_in_two_launches"] == (c.num_layers() > 1)
+        whole = c.process_batch(prev, nxt, smp)
+        assert np.array_equal(whole["flow"], ref["flow"]) and whole["results"].tobytes() == ref["results"].tobytes()
+        seq = synth.make_sequence(W, H, batch + 1)                       # a frame sequence through the same form
+        c.set_option("small_batch", 0)
+        seq_ref = c.farneback_sequence(seq)
+        c.set_option("small_batch", 1)
+        assert np.array_equal(c.farneback_sequence(seq), seq_ref)
         for rep in range(2):
             for b in range(batch):
                 one = c.process_batch(prev[b:b + 1], nxt[b:b + 1], smp[b:b + 1])
@@ -341,7 +353,7 @@ def test_options_are_reported_and_validated(mav):
         assert info["layers"][0]["sweeps"].startswith("two pairs in flight") and info["layers"][0]["bands"] == 2
         assert info["layers"][1]["blur"] == "fused" and info["layers"][1]["pairs_per_launch"] == 4
         for name, v in (("band_mb", 40), ("coarse_half", 3), ("strip", 20), ("phi_yloop", 4), ("phi_screen", 0), ("share_m", 0),
-                        ("coarse_cache_mb", 100), ("bands", 3), ("group_fine", 2)):
+                        ("coarse_cache_mb", 100), ("bands", 3), ("group_fine", 2), ("small_batch", 0)):
             c.set_option(name, v)
             assert c.get_option(name) == v
             assert c.schedule_info(64)[name] == v
