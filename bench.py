@@ -168,20 +168,27 @@ def run_config_leg(name, W, H, B, levels, calls, pairs_to_check, verify=True):
     def call():
         ctx.process_batch_dev(d_prev.ptr, d_next.ptr, d_smp.ptr, B, d_res.ptr, mf_ptr=d_mf.ptr, md_ptr=d_md.ptr)
 
-    for _ in range(max(3, calls // 20)):
+    for _ in range(max(10, calls // 2)):               # (the first calls after an idle phase run slower: clocks ramp up)
         call()
     ctx.sync()
-    t0 = time.perf_counter()
-    ctx.timer_start()
-    for _ in range(calls):
-        call()
-    ev_ms = ctx.timer_stop()
-    ctx.sync()
-    wall_ms = 1e3 * (time.perf_counter() - t0)
+    # three repetitions of `calls` back-to-back calls; the median repetition is reported (a launch-latency-bound chain of ~27 small
+    # kernels per call is sensitive to the clock state the preceding legs left the GPU in), all three are listed
+    reps = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        ctx.timer_start()
+        for _ in range(calls):
+            call()
+        ev = ctx.timer_stop()
+        ctx.sync()
+        reps.append((ev, 1e3 * (time.perf_counter() - t0)))
+    ev_ms, wall_ms = sorted(reps)[1]
     balg = b_alg_per_pair(layers, W, H, ctx.fb.iterations)
     per_pair_ms = ev_ms / calls / B
-    out = {"workload": f"{W}x{H}, batch={B}, levels={levels} ({len(layers)} pyramid layers), {calls} back-to-back mav_process_batch_dev calls, frames resident",
+    out = {"workload": f"{W}x{H}, batch={B}, levels={levels} ({len(layers)} pyramid layers), 3 x {calls} back-to-back mav_process_batch_dev calls "
+                       f"(median repetition reported), frames resident",
            "ms_per_call_hip_events": round(ev_ms / calls, 4), "ms_per_call_wall": round(wall_ms / calls, 4),
+           "ms_per_call_hip_events_all_reps": [round(e / calls, 4) for e, _ in reps],
            "ms_per_pair": round(per_pair_ms, 4), "pairs_per_s": round(B * calls / (wall_ms * 1e-3), 2),
            "alg_bytes_per_pair": balg, "frac": round(balg / (per_pair_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
            "frac_is": "whole-pipeline algorithmic bytes (SURVEY 8d) / HIP-event time / 8 TB/s",
@@ -340,17 +347,15 @@ def main():
         assert allrec[rank * B:(rank + 1) * B].tobytes() == res_last.tobytes(), "all-gathered records differ from the local ones"
     if rank == 0 and not args.no_verify:
         verification = verify_last_step(ctx, prev, nxt, samples, res_last, d_mf, d_md, sorted({0, B - 1}), args.levels)
-        # ... and EVERY pair of the timed step against the same batch re-run in the plain schedule (one stream, sweep-major, one group
-        # at a time: the form the parity tests check against the oracle): records, both masks and the whole flow must be identical
+        # ... and EVERY pair of the timed step against the same batch re-run in the plain schedule (one stream, one pair after the other: the form the parity tests check against the oracle): records, both masks and the whole flow must be identical
         import zlib
 
         def digest():
             return (d_res.download(np.uint8, (B * rec,)).tobytes(), zlib.crc32(d_mf.download(np.uint8, (B * W * H,))),
                     zlib.crc32(d_md.download(np.uint8, (B * W * H,))), [zlib.crc32(ctx.last_flow(b)) for b in range(B)])
         timed = digest()
-        saved = {k: ctx.get_option(k) for k in ("pairs_in_flight", "bands")}
+        saved = {k: ctx.get_option(k) for k in ("pairs_in_flight",)}
         ctx.set_option("pairs_in_flight", 1)
-        ctx.set_option("bands", 1)
         run_batch()
         ctx.sync()
         plain = digest()
@@ -501,8 +506,8 @@ def main():
     configs = None
     if rank == 0 and world == 1 and not args.no_configs and (W, H, args.levels) == (1920, 1080, 1):
         d_prev.free(); d_next.free(); d_mf.free(); d_md.free()         # (the headline's buffers are no longer needed)
-        configs = {"C2": run_config_leg("C2", 1280, 720, 1, 1, 400, [0], verify=not args.no_verify),
-                   "C5_share": run_config_leg("C5_share", 3840, 2160, 16, 5, 12, [0, 15], verify=not args.no_verify)}
+        configs = {"C2": run_config_leg("C2", 1280, 720, 1, 1, 300, [0], verify=not args.no_verify),
+                   "C5_share": run_config_leg("C5_share", 3840, 2160, 16, 5, 10, [0, 15], verify=not args.no_verify)}
         configs["C5_share"]["note"] = "per-GPU share of BASELINE config 5 (batch 128 across 8 GPUs); its CPU baseline (73 s) is not repeated here"
 
     failed = False

@@ -82,8 +82,9 @@ int mav_device_count(void);       /* <= 0 when no GPU is visible */
  *                      band by band (bands of <= "band_mb" MB of working set, default 86, or "bands" when set) so that both stay in
  *                      the Infinity Cache; the coarse layers alternate sub-groups of "coarse_half" pairs (0 = half the count that fits
  *                      "coarse_cache_mb", default 220) between the two streams
- *   "bands"            J in [1, 8]: a pair's finest-layer sweeps run band by band over J skewed horizontal bands (default: 1 up to
- *                      ~2.6 Mpx, above that as many as keep a band's working set inside the Infinity Cache)
+ *   "bands"            J in [1, 8]: a pair's finest-layer sweeps run band by band over J skewed horizontal bands; 0 = automatic (the
+ *                      default: 1 up to ~2.6 Mpx, above that as many as keep a band's working set inside the Infinity Cache; the
+ *                      two-stream schedule sizes its bands by "band_mb")
  *   "share_m"          one-stream schedule: all pairs of a group ping-pong M through the first slot's buffers (default 1)
  *   "share_frames"     0: treat a frame sequence (see mav_farneback) as independent pairs (default 1)
  *   "small_batch"      default 1: a group whose finest-layer working set is at most 200 MB (one 1080p pair, two 720p pairs: a chain of

@@ -216,6 +216,7 @@ struct mav_ctx {
     // compute stream and pair_stream, every pair band-major over bands of at most pif_band_mb of working set (layer_sweeps)
     int pairs_in_flight = 2, pif_band_mb = 86;
     bool bands_set = false;          // "bands" given explicitly: that many bands in either schedule
+    int bands_auto = 1;              // what "bands" = 0 restores
     bool group_fine_set = false;     // "group_fine" given explicitly
     hipStream_t pair_stream = nullptr;
     hipEvent_t pif_fork = nullptr, pif_join = nullptr;
@@ -446,6 +447,7 @@ extern "C" int mav_create(mav_ctx** out, int device, int W, int H, int max_batch
         c->bands = (int)(((size_t)W * H * 80 + ((size_t)230 << 20) - 1) / ((size_t)230 << 20));
         if (c->bands > 8) c->bands = 8;
     }
+    c->bands_auto = c->bands;
     rc = alloc_group(c, group);
     if (rc != MAV_OK) return bail(rc);
     const size_t B = (size_t)max_batch;
@@ -466,7 +468,7 @@ extern "C" int mav_create(mav_ctx** out, int device, int W, int H, int max_batch
 // ---- options: every scheduling / tuning switch of the library lives here (no environment variables) -----------------------------
 struct OptionDesc { const char* name; long lo, hi; };
 static const OptionDesc kOptions[] = {
-    {"group", 1, 1 << 20}, {"group_fine", 0, 1 << 20}, {"bands", 1, 8}, {"pairs_in_flight", 1, 2}, {"band_mb", 8, 1 << 20},
+    {"group", 1, 1 << 20}, {"group_fine", 0, 1 << 20}, {"bands", 0, 8}, {"pairs_in_flight", 1, 2}, {"band_mb", 8, 1 << 20},
     {"coarse_cache_mb", 0, 1 << 20}, {"coarse_half", 0, 1 << 20}, {"share_m", 0, 1}, {"share_frames", 0, 1}, {"strip", 0, 1 << 20},
     {"phi_screen", 0, 1}, {"phi_yloop", 0, 1 << 20}, {"small_batch", 0, 1},
 };
@@ -505,7 +507,10 @@ extern "C" int mav_set_option(mav_ctx* c, const char* name, long value)
         return g == c->group ? MAV_OK : alloc_group(c, g);
     }
     if (!strcmp(name, "group_fine")) { c->group_fine = v; c->group_fine_set = true; }
-    else if (!strcmp(name, "bands")) { c->bands = v; c->bands_set = true; }
+    else if (!strcmp(name, "bands")) {          // 0 = back to automatic
+        c->bands_set = v > 0;
+        c->bands = v > 0 ? v : c->bands_auto;
+    }
     else if (!strcmp(name, "pairs_in_flight")) c->pairs_in_flight = v;
     else if (!strcmp(name, "band_mb")) c->pif_band_mb = v;
     else if (!strcmp(name, "coarse_cache_mb")) c->coarse_cache_mb = v;

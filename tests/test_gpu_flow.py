@@ -357,6 +357,10 @@ def test_options_are_reported_and_validated(mav):
             c.set_option(name, v)
             assert c.get_option(name) == v
             assert c.schedule_info(64)[name] == v
+        c.set_option("bands", 0)                                     # back to automatic
+        c.set_option("group_fine", 1)
+        c.set_option("band_mb", 86)
+        assert c.schedule_info(64)["layers"][0]["bands"] == 2
         for name, v in (("pairs_in_flight", 3), ("bands", 9), ("group", 0), ("no_such_option", 1), ("recompute", 1), ("pipeline", 1)):
             with pytest.raises(ValueError):
                 c.set_option(name, v)

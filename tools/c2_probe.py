@@ -32,4 +32,11 @@ for rep in range(3):
         call()
     best.append(ctx.timer_stop() / CALLS)
 print(f"{W}x{H} batch {B} {dict(opts)}: GPU ms per call, back to back: " + " ".join(f"{t:.4f}" for t in best), flush=True)
+import time
+ctx.sync()
+enq = []
+for _ in range(50):
+    t0 = time.perf_counter(); call(); enq.append(time.perf_counter() - t0); ctx.sync()
+enq = np.array(enq) * 1e3
+print(f"    host enqueue per call (idle stream): median {np.median(enq):.4f} ms, min {enq.min():.4f}", flush=True)
 ctx.close()

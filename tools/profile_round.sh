@@ -1,12 +1,14 @@
 #!/bin/bash
 # Everything profiles/<round>/ holds, measured on the box this runs on:   tools/profile_round.sh <outdir>
-#   kernel-trace stats of the default bench (1080p, batch 64) and of the 4K / 5-layer shape, PMC passes of both, traffic records.
+#   kernel-trace stats of the default bench (1080p, batch 64) and of the 4K / 5-layer shape, PMC passes of both, traffic records,
+#   the sweeps' busy-time unions, the step anatomy, and one BASELINE-config-2 call (1280x720, one pair) launch by launch.
 set -u
 export TMPDIR=/tmp
 out=$1; mkdir -p "$out"
 B4K="--width 3840 --height 2160 --levels 5 --batch 16"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt1080" -- python3 bench.py --steps 5 --warmup 2 --cpu-pairs 0 --no-configs --no-verify > "$out/kt1080.json" 2> "$out/kt1080.err" || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt4k" -- python3 bench.py --steps 5 --warmup 2 --cpu-pairs 0 --no-configs --no-verify $B4K > "$out/kt4k.json" 2> "$out/kt4k.err" || exit 1
+timeout -k 10 120 rocprofv3 --kernel-trace --output-format csv -d "$out/ktc2" -- python3 tools/c2_probe.py 1280 720 1 50 > "$out/ktc2.log" 2>&1 || exit 1
 tools/pmc_passes.sh "$out/pmc1080" --batch 64 > "$out/pmc1080.log" 2>&1 || exit 1
 tools/pmc_passes.sh "$out/pmc4k" $B4K > "$out/pmc4k.log" 2>&1 || exit 1
 python3 tools/make_traffic.py "$out/pmc1080" "$out/traffic.json" --batch 64 > /dev/null || exit 1
@@ -15,5 +17,7 @@ python3 tools/make_traffic.py "$out/pmc4k" "$out/traffic_4k.json" --width 3840 -
 for t in kt1080 kt4k; do
   per=$(python3 -c "import json,sys; print(json.loads(open('$out/$t.json').readline())['roofline']['alg_bytes_per_launch_avg'])")
   python3 tools/trace_union.py "$out"/$t/runc/*_kernel_trace.csv --bytes-per-dispatch "$per" > "$out/sweep_busy_$t.txt" || exit 1
+  python3 tools/step_anatomy.py "$out"/$t/runc/*_kernel_trace.csv 3 > "$out/step_anatomy_$t.txt" || exit 1
 done
+python3 tools/trace_timeline.py "$out"/ktc2/runc/*_kernel_trace.csv --last 27 > "$out/c2_timeline.txt" || exit 1
 find "$out" -name "*kernel_stats.csv" | head
