@@ -90,6 +90,8 @@ int mav_device_count(void);       /* <= 0 when no GPU is visible */
  *   "small_batch"      default 1: a group whose finest-layer working set is at most 200 MB (one 1080p pair, two 720p pairs: a chain of
  *                      launches that each fill a fraction of the chip) gets the layer images of its whole pyramid from ONE launch and
  *                      all polynomial expansions from ONE launch instead of two launches per layer
+ *   "sweep_write_through"  -1 (default): the sweeps' M' stores are write-through (sc1) in the two-stream schedules, plain otherwise;
+ *                      0 / 1: never / always
  *   "strip"            width in tiles of the column strips of the XCD-aware tile order (0 = automatic)
  *   "phi_screen"       0: every pixel of the phi / threshold stage takes the exact path (default 1: float32 screen in front of it)
  *   "phi_yloop"        16-row blocks per workgroup of the phi kernel (0 = automatic)

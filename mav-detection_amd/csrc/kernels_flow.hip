@@ -93,6 +93,7 @@ extern "C" int mav_debug_read_stamps(unsigned long long* out, int reset)
 // the 5-tap one.
 static __device__ __forceinline__ void resize_coord(int o, int S, int d, double scale, int* s0, float* f)
 {
+#pragma clang fp contract(off)                       // (o + 0.5) * scale - 0.5 with separate roundings, as OpenCV's host code evaluates it
     if (d == S) { *s0 = o; *f = 0.f; return; }
     float t = (float)((o + 0.5) * scale - 0.5);
     int s = (int)floorf(t);
@@ -710,12 +711,12 @@ static __device__ __forceinline__ void polyexp_tile(const float* __restrict__ sr
         const float* c = tile + (ly + n) * EX + lx;
         float t0 = c[0] * pc.g[0], t1 = 0.f, t2 = 0.f;
 #pragma unroll
-        for (int k = 1; k <= n; k++) {
+        for (int k = 1; k <= n; k++) {               // (explicit fmaf: the bits must not depend on which kernel this is inlined into)
             const float a = c[-k * EX], b = c[k * EX];
             const float p = a + b;
-            t0 += pc.g[k] * p;
-            t1 += pc.xg[k] * (b - a);
-            t2 += pc.xxg[k] * p;
+            t0 = fmaf(pc.g[k], p, t0);
+            t1 = fmaf(pc.xg[k], b - a, t1);
+            t2 = fmaf(pc.xxg[k], p, t2);
         }
         v0[i] = t0; v1[i] = t1; v2[i] = t2;
     }
@@ -733,18 +734,18 @@ static __device__ __forceinline__ void polyexp_tile(const float* __restrict__ sr
         for (int k = 1; k <= n; k++) {
             const float a0 = p0[-k], c0 = p0[k], a1 = p1[-k], c1 = p1[k], a2 = p2[-k], c2 = p2[k];
             const float tg = c0 + a0;
-            b1 += tg * pc.g[k];
-            b4 += tg * pc.xxg[k];
-            b2 += (c0 - a0) * pc.xg[k];
-            b3 += (c1 + a1) * pc.g[k];
-            b6 += (c1 - a1) * pc.xg[k];
-            b5 += (c2 + a2) * pc.g[k];
+            b1 = fmaf(tg, pc.g[k], b1);
+            b4 = fmaf(tg, pc.xxg[k], b4);
+            b2 = fmaf(c0 - a0, pc.xg[k], b2);
+            b3 = fmaf(c1 + a1, pc.g[k], b3);
+            b6 = fmaf(c1 - a1, pc.xg[k], b6);
+            b5 = fmaf(c2 + a2, pc.g[k], b5);
         }
         const size_t o = (size_t)gy * w + gx;
         dst[o] = b3 * pc.ig11;
         dst[npx + o] = b2 * pc.ig11;
-        dst[2 * npx + o] = b1 * pc.ig03 + b5 * pc.ig33;
-        dst[3 * npx + o] = b1 * pc.ig03 + b4 * pc.ig33;
+        dst[2 * npx + o] = fmaf(b5, pc.ig33, b1 * pc.ig03);
+        dst[3 * npx + o] = fmaf(b4, pc.ig33, b1 * pc.ig03);
         dst[4 * npx + o] = b6 * pc.ig55;
     }
 }
@@ -816,18 +817,24 @@ void launch_polyexp(hipStream_t st, const float* I, size_t I_stride, int G, int 
 static __device__ __forceinline__ void update_core(const float q[5], const float* __restrict__ R1p, size_t npx, int w, int h,
                                                    int x, int y, float dx, float dy, float out[5])
 {
+    // Every multiply-add below is spelled out (fmaf) and contraction is off for the rest: the bits must not depend on which kernel
+    // (or which template instantiation of one) the function is inlined into -- under the file's default -ffp-contract=fast two
+    // instantiations of the sweep kernel that differed in a store instruction fused `a*b + c*d` differently and their flows drifted
+    // apart by up to 8e-4 px over twenty sweeps.  update_finish() below is the same arithmetic on values already gathered.
+#pragma clang fp contract(off)
     float fx = x + dx, fy = y + dy;
     const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
     fx -= x1; fy -= y1;
     float r2, r3, r4, r5, r6;
     if ((unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1)) {
-        const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+        const float gx = 1.f - fx, gy = 1.f - fy;
+        const float a00 = gx * gy, a01 = fx * gy, a10 = gx * fy, a11 = fx * fy;
         const float* p = R1p + (size_t)y1 * w + x1;
-        r2 = a00 * p[0] + a01 * p[1] + a10 * p[w] + a11 * p[w + 1]; p += npx;
-        r3 = a00 * p[0] + a01 * p[1] + a10 * p[w] + a11 * p[w + 1]; p += npx;
-        r4 = a00 * p[0] + a01 * p[1] + a10 * p[w] + a11 * p[w + 1]; p += npx;
-        r5 = a00 * p[0] + a01 * p[1] + a10 * p[w] + a11 * p[w + 1]; p += npx;
-        r6 = a00 * p[0] + a01 * p[1] + a10 * p[w] + a11 * p[w + 1];
+        r2 = fmaf(a11, p[w + 1], fmaf(a10, p[w], fmaf(a01, p[1], a00 * p[0]))); p += npx;
+        r3 = fmaf(a11, p[w + 1], fmaf(a10, p[w], fmaf(a01, p[1], a00 * p[0]))); p += npx;
+        r4 = fmaf(a11, p[w + 1], fmaf(a10, p[w], fmaf(a01, p[1], a00 * p[0]))); p += npx;
+        r5 = fmaf(a11, p[w + 1], fmaf(a10, p[w], fmaf(a01, p[1], a00 * p[0]))); p += npx;
+        r6 = fmaf(a11, p[w + 1], fmaf(a10, p[w], fmaf(a01, p[1], a00 * p[0])));
         r4 = (q[2] + r4) * 0.5f;
         r5 = (q[3] + r5) * 0.5f;
         r6 = (q[4] + r6) * 0.25f;
@@ -837,8 +844,8 @@ static __device__ __forceinline__ void update_core(const float q[5], const float
     }
     r2 = (q[0] - r2) * 0.5f;
     r3 = (q[1] - r3) * 0.5f;
-    r2 += r4 * dy + r6 * dx;
-    r3 += r6 * dy + r5 * dx;
+    r2 += fmaf(r4, dy, r6 * dx);
+    r3 += fmaf(r6, dy, r5 * dx);
     const int BORDER = 5;
     if ((unsigned)(x - BORDER) >= (unsigned)(w - BORDER * 2) || (unsigned)(y - BORDER) >= (unsigned)(h - BORDER * 2)) {
         // border[] = {0.14, 0.14, 0.4472, 0.4472, 0.4472}
@@ -847,11 +854,11 @@ static __device__ __forceinline__ void update_core(const float q[5], const float
                             (y < BORDER ? bw(y) : 1.f) * (y >= h - BORDER ? bw(h - y - 1) : 1.f);
         r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
     }
-    out[0] = r4 * r4 + r6 * r6;
+    out[0] = fmaf(r4, r4, r6 * r6);
     out[1] = (r4 + r5) * r6;
-    out[2] = r5 * r5 + r6 * r6;
-    out[3] = r4 * r2 + r6 * r3;
-    out[4] = r6 * r2 + r5 * r3;
+    out[2] = fmaf(r5, r5, r6 * r6);
+    out[3] = fmaf(r4, r2, r6 * r3);
+    out[4] = fmaf(r6, r2, r5 * r3);
 }
 
 // memory form: R0p/R1p/Mp point at plane 0 of the pair; planes are npx apart.
@@ -884,6 +891,7 @@ static __device__ __forceinline__ void solve_px(float g11, float g12, float g22,
 static __device__ __forceinline__ float2 upsample_flow(const float* __restrict__ pf, int pw, int ph, float mul, double scale_x,
                                                        double scale_y, int x, int y)
 {
+#pragma clang fp contract(off)                       // products and sums rounded one by one, as resize()'s host code does
     float fy = (float)((y + 0.5) * scale_y - 0.5);
     int sy = (int)floorf(fy);
     fy -= sy;
@@ -1101,14 +1109,16 @@ static __device__ __forceinline__ void gather_issue(const float* __restrict__ R1
 static __device__ __forceinline__ void update_finish(const float q[5], const GatherPx& g, int w, int h, int x, int y, float dx,
                                                      float dy, float out[5])
 {
+#pragma clang fp contract(off)                       // explicit fmaf only: see update_core()
     float r2, r3, r4, r5, r6;
     if (g.inside) {
-        const float a00 = (1.f - g.fx) * (1.f - g.fy), a01 = g.fx * (1.f - g.fy), a10 = (1.f - g.fx) * g.fy, a11 = g.fx * g.fy;
-        r2 = a00 * g.p00[0] + a01 * g.p01[0] + a10 * g.p10[0] + a11 * g.p11[0];
-        r3 = a00 * g.p00[1] + a01 * g.p01[1] + a10 * g.p10[1] + a11 * g.p11[1];
-        r4 = a00 * g.p00[2] + a01 * g.p01[2] + a10 * g.p10[2] + a11 * g.p11[2];
-        r5 = a00 * g.p00[3] + a01 * g.p01[3] + a10 * g.p10[3] + a11 * g.p11[3];
-        r6 = a00 * g.p00[4] + a01 * g.p01[4] + a10 * g.p10[4] + a11 * g.p11[4];
+        const float gx = 1.f - g.fx, gy = 1.f - g.fy;
+        const float a00 = gx * gy, a01 = g.fx * gy, a10 = gx * g.fy, a11 = g.fx * g.fy;
+        r2 = fmaf(a11, g.p11[0], fmaf(a10, g.p10[0], fmaf(a01, g.p01[0], a00 * g.p00[0])));
+        r3 = fmaf(a11, g.p11[1], fmaf(a10, g.p10[1], fmaf(a01, g.p01[1], a00 * g.p00[1])));
+        r4 = fmaf(a11, g.p11[2], fmaf(a10, g.p10[2], fmaf(a01, g.p01[2], a00 * g.p00[2])));
+        r5 = fmaf(a11, g.p11[3], fmaf(a10, g.p10[3], fmaf(a01, g.p01[3], a00 * g.p00[3])));
+        r6 = fmaf(a11, g.p11[4], fmaf(a10, g.p10[4], fmaf(a01, g.p01[4], a00 * g.p00[4])));
         r4 = (q[2] + r4) * 0.5f;
         r5 = (q[3] + r5) * 0.5f;
         r6 = (q[4] + r6) * 0.25f;
@@ -1118,8 +1128,8 @@ static __device__ __forceinline__ void update_finish(const float q[5], const Gat
     }
     r2 = (q[0] - r2) * 0.5f;
     r3 = (q[1] - r3) * 0.5f;
-    r2 += r4 * dy + r6 * dx;
-    r3 += r6 * dy + r5 * dx;
+    r2 += fmaf(r4, dy, r6 * dx);
+    r3 += fmaf(r6, dy, r5 * dx);
     const int BORDER = 5;
     if ((unsigned)(x - BORDER) >= (unsigned)(w - BORDER * 2) || (unsigned)(y - BORDER) >= (unsigned)(h - BORDER * 2)) {
         auto bw = [](int d) { return d < 2 ? 0.14f : 0.4472f; };
@@ -1127,17 +1137,24 @@ static __device__ __forceinline__ void update_finish(const float q[5], const Gat
                             (y < BORDER ? bw(y) : 1.f) * (y >= h - BORDER ? bw(h - y - 1) : 1.f);
         r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
     }
-    out[0] = r4 * r4 + r6 * r6;
+    out[0] = fmaf(r4, r4, r6 * r6);
     out[1] = (r4 + r5) * r6;
-    out[2] = r5 * r5 + r6 * r6;
-    out[3] = r4 * r2 + r6 * r3;
-    out[4] = r6 * r2 + r5 * r3;
+    out[2] = fmaf(r5, r5, r6 * r6);
+    out[3] = fmaf(r4, r2, r6 * r3);
+    out[4] = fmaf(r6, r2, r5 * r3);
 }
 
 struct __attribute__((packed, aligned(4))) F2U { float x, y; };     // two adjacent floats at 4-byte alignment
 // AL = true: width a multiple of 4 and 16-byte aligned planes (vector loads / stores as written); AL = false: any width -- the
 // column pairs are read as two floats at 4-byte alignment and the flow is stored pixel by pixel.
-template <int M_T, bool AL = true>
+// WT = true: M' leaves the kernel through write-through (agent-scope, sc1) stores instead of staying dirty in the XCD's L2 until the
+// end-of-kernel write-back.  With two launches in flight on two streams (the batch schedules) that is worth 2 % of a step -- 1080p,
+// 64 pairs: 2 532 -> 2 577 pairs/s over three alternating runs, 4K / 5 layers, 16 pairs: 571 -> 583 (profiles/r03/ab_write_through.log) --
+// the lines M' would occupy in L2 stay free for the M / R0 / R1 reads and no launch ends in a burst of write-backs that its
+// neighbour on the other stream has to share; alone on one stream (one pair per call) the same stores cost 3 % (0.305 vs 0.297 ms
+// per 1280x720 pair), so launch_blur_iter's callers ask for it in the two-stream schedules only.  Write-through for the initial M
+// (k_update_matrices) and for the expansions (k_polyexp) was measured too: -0.7 % and +-0.
+template <int M_T, bool AL = true, bool WT = false>
 __global__ __launch_bounds__(256) void k_blur_iter_fast(const float* __restrict__ M_in, float* __restrict__ M_out,
                                                         size_t M_stride, const float* __restrict__ R0,
                                                         const float* __restrict__ R1, size_t R_stride, int w, int h,
@@ -1300,7 +1317,10 @@ __global__ __launch_bounds__(256) void k_blur_iter_fast(const float* __restrict_
             if (colok && y0 + wv * 4 + jb + jj < h) {
                 const size_t idx = (size_t)gys[jb + jj] * w + gxc;
 #pragma unroll
-                for (int c = 0; c < 5; c++) Mo[c * npx + idx] = o[c];
+                for (int c = 0; c < 5; c++) {
+                    if constexpr (WT) __hip_atomic_store((unsigned*)(Mo + c * npx + idx), __float_as_uint(o[c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else Mo[c * npx + idx] = o[c];
+                }
             }
         }
 #ifdef MAV_STAMPS
@@ -1328,7 +1348,7 @@ bool blur_iter_bands_ok(int w, int winsize, size_t M_stride, size_t R_stride, si
 // tile rows [ty0, ty1) only (ty1 < 0: the whole layer).  Band launches exist for the fast form only (blur_iter_bands_ok).
 void launch_blur_iter(hipStream_t st, const float* M_in, float* M_out, size_t M_stride, const float* R0, const float* R1,
                       size_t R_stride, int G, int w, int h, int winsize, int do_update, int store_flow, float* flow, size_t f_stride,
-                      int ty0, int ty1, int strip)
+                      int ty0, int ty1, int strip, bool write_through)
 {
     int ext, pitch, plane;
     const int m = winsize / 2;
@@ -1338,14 +1358,22 @@ void launch_blur_iter(hipStream_t st, const float* M_in, float* M_out, size_t M_
     if (m == 6 && vec_ok) {
         const TileMap tm = make_tile_map(w, h, G, FT_X, FT_Y, ty0, ty1, strip);
         if (tm.n_tiles == 0) return;
-        hipLaunchKernelGGL(k_blur_iter_fast<6>, dim3(tile_grid(tm)), dim3(256), 0, st, M_in, M_out, M_stride, R0, R1, R_stride, w, h,
-                           tm, scale, do_update, store_flow, flow, f_stride);
+        if (write_through && do_update)
+            hipLaunchKernelGGL((k_blur_iter_fast<6, true, true>), dim3(tile_grid(tm)), dim3(256), 0, st, M_in, M_out, M_stride, R0, R1, R_stride, w,
+                               h, tm, scale, do_update, store_flow, flow, f_stride);
+        else
+            hipLaunchKernelGGL(k_blur_iter_fast<6>, dim3(tile_grid(tm)), dim3(256), 0, st, M_in, M_out, M_stride, R0, R1, R_stride, w, h,
+                               tm, scale, do_update, store_flow, flow, f_stride);
         return;
     }
     if (m == 6 && f_stride % 2 == 0 && ((uintptr_t)flow & 7) == 0) {    // any width / alignment: relaxed form of the same kernel
         const TileMap tm = make_tile_map(w, h, G, FT_X, FT_Y, 0, -1, strip);
-        hipLaunchKernelGGL((k_blur_iter_fast<6, false>), dim3(tile_grid(tm)), dim3(256), 0, st, M_in, M_out, M_stride, R0, R1, R_stride,
-                           w, h, tm, scale, do_update, store_flow, flow, f_stride);
+        if (write_through && do_update)
+            hipLaunchKernelGGL((k_blur_iter_fast<6, false, true>), dim3(tile_grid(tm)), dim3(256), 0, st, M_in, M_out, M_stride, R0, R1, R_stride,
+                               w, h, tm, scale, do_update, store_flow, flow, f_stride);
+        else
+            hipLaunchKernelGGL((k_blur_iter_fast<6, false>), dim3(tile_grid(tm)), dim3(256), 0, st, M_in, M_out, M_stride, R0, R1, R_stride,
+                               w, h, tm, scale, do_update, store_flow, flow, f_stride);
         return;
     }
     iter_geometry(m, &ext, &pitch, &plane);

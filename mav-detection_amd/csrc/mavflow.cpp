@@ -210,6 +210,7 @@ struct mav_ctx {
     size_t c_total = 0;
     int small_g = 0;                          // pairs the Ic / Rc buffers were sized for (0: none)
     bool small_batch = true;                  // option "small_batch"
+    int sweep_wt = -1;                        // option "sweep_write_through": -1 = in the two-stream schedules only (default), 0 / 1 = never / always
     int small_batch_mb = 200;                 // option "small_batch_mb": ... for groups of at most this much finest-layer sweep working set
     int bands = 1;                   // option "bands": the finest layer's sweeps in band-major order over this many skewed bands
     // option "pairs_in_flight" (1 or 2): the finest layer's per-pair work (initial M + sweeps) of a group alternates between the
@@ -470,7 +471,7 @@ struct OptionDesc { const char* name; long lo, hi; };
 static const OptionDesc kOptions[] = {
     {"group", 1, 1 << 20}, {"group_fine", 0, 1 << 20}, {"bands", 0, 8}, {"pairs_in_flight", 1, 2}, {"band_mb", 8, 1 << 20},
     {"coarse_cache_mb", 0, 1 << 20}, {"coarse_half", 0, 1 << 20}, {"share_m", 0, 1}, {"share_frames", 0, 1}, {"strip", 0, 1 << 20},
-    {"phi_screen", 0, 1}, {"phi_yloop", 0, 1 << 20}, {"small_batch", 0, 1},
+    {"phi_screen", 0, 1}, {"phi_yloop", 0, 1 << 20}, {"small_batch", 0, 1}, {"sweep_write_through", -1, 1},
 };
 static long* option_slot(mav_ctx* c, const char* name, long* tmp)
 {
@@ -479,7 +480,7 @@ static long* option_slot(mav_ctx* c, const char* name, long* tmp)
         {"group", c->group}, {"group_fine", c->group_fine}, {"bands", c->bands}, {"pairs_in_flight", c->pairs_in_flight},
         {"band_mb", c->pif_band_mb}, {"coarse_cache_mb", c->coarse_cache_mb}, {"coarse_half", c->coarse_half}, {"share_m", c->share_m},
         {"share_frames", c->share_frames}, {"strip", c->strip}, {"phi_screen", c->phi_screen}, {"phi_yloop", c->phi_yloop},
-        {"small_batch", c->small_batch},
+        {"small_batch", c->small_batch}, {"sweep_write_through", c->sweep_wt},
     };
     for (auto& e : cur) if (!strcmp(e.n, name)) { *tmp = e.v; return tmp; }
     return nullptr;
@@ -521,6 +522,7 @@ extern "C" int mav_set_option(mav_ctx* c, const char* name, long value)
     else if (!strcmp(name, "phi_screen")) c->phi_screen = v != 0;
     else if (!strcmp(name, "phi_yloop")) c->phi_yloop = v;
     else if (!strcmp(name, "small_batch")) c->small_batch = v != 0;
+    else if (!strcmp(name, "sweep_write_through")) c->sweep_wt = v;
     return MAV_OK;
 }
 
@@ -812,8 +814,9 @@ static SweepPlan plan_sweeps(const mav_ctx* c, int k, int g, bool bands_ok)
 // simply built twice, to the same values.
 struct BandUpdate { const float* flow_prev; size_t fc_stride; int pw, ph; float mul; };
 static void sweeps_band_major(mav_ctx* c, hipStream_t st, int kid, float* Ma, float* Mb, const float* r0, const float* r1, size_t rs, int gs,
-                              int lw, int lh, int T, int J, float* fo, size_t fstride, const BandUpdate* upd = nullptr)
+                              int lw, int lh, int T, int J, float* fo, size_t fstride, const BandUpdate* upd = nullptr, bool two_streams = false)
 {
+    const bool wt = c->sweep_wt < 0 ? two_streams : c->sweep_wt != 0;
     const size_t n0 = c->n0;
     const int I = c->fb.iterations;
     for (int j = 0; j < J; j++) {
@@ -830,20 +833,21 @@ static void sweeps_band_major(mav_ctx* c, hipStream_t st, int kid, float* Ma, fl
             if (ty1 <= ty0) continue;
             ProfScope ps(c, kid, st);
             launch_blur_iter(st, (it & 1) ? Mb : Ma, (it & 1) ? Ma : Mb, 5 * n0, r0, r1, rs, gs, lw, lh, c->fb.winsize, update, !update, fo,
-                             fstride, ty0, ty1, c->strip);
+                             fstride, ty0, ty1, c->strip, wt);
         }
     }
 }
 
 // initial M + the `iterations` sweeps of gs pairs, sweep-major, on stream ss
 static void sweeps_plain(mav_ctx* c, hipStream_t ss, int kid, float* Min, float* Mout, const float* r0, const float* r1, size_t rs, int gs,
-                         const Layer& l, float* fo, size_t fstride)
+                         const Layer& l, float* fo, size_t fstride, bool two_streams = false)
 {
     const size_t n0 = c->n0;
+    const bool wt = c->sweep_wt < 0 ? two_streams : c->sweep_wt != 0;
     for (int it = 0; it < c->fb.iterations; it++) {
         const int update = it < c->fb.iterations - 1;
         { ProfScope ps(c, kid, ss);
-          launch_blur_iter(ss, Min, Mout, 5 * n0, r0, r1, rs, gs, l.w, l.h, c->fb.winsize, update, !update, fo, fstride, 0, -1, c->strip); }
+          launch_blur_iter(ss, Min, Mout, 5 * n0, r0, r1, rs, gs, l.w, l.h, c->fb.winsize, update, !update, fo, fstride, 0, -1, c->strip, wt); }
         if (update) { float* t = Min; Min = Mout; Mout = t; }
     }
 }
@@ -872,12 +876,12 @@ static int layer_sweeps(mav_ctx* c, hipStream_t st, int k, int g, const float* r
             float* fo = fdst + (size_t)s0 * fstride;
             const BandUpdate bu{flow_prev ? flow_prev + (size_t)s0 * fc_stride : nullptr, fc_stride, pw, ph, mul};
             if (p.J > 1) {
-                sweeps_band_major(c, ss, K_ITER, Min, Mout, r0, r1, rs, 1, l.w, l.h, T, p.J, fo, fstride, &bu);
+                sweeps_band_major(c, ss, K_ITER, Min, Mout, r0, r1, rs, 1, l.w, l.h, T, p.J, fo, fstride, &bu, true);
                 continue;
             }
             { ProfScope ps(c, K_UPDATE, ss);
               launch_update_matrices(ss, r0, r1, rs, bu.flow_prev, fc_stride, pw, ph, mul, 1, l.w, l.h, Min, 5 * n0); }
-            sweeps_plain(c, ss, K_ITER, Min, Mout, r0, r1, rs, 1, l, fo, fstride);
+            sweeps_plain(c, ss, K_ITER, Min, Mout, r0, r1, rs, 1, l, fo, fstride, true);
         }
         prof_close_stream(c, c->pair_stream); prof_close_stream(c, st);
         HIPCHK(hipEventRecord(c->pif_join, c->pair_stream));
@@ -896,7 +900,7 @@ static int layer_sweeps(mav_ctx* c, hipStream_t st, int k, int g, const float* r
             { ProfScope ps(c, K_UPDATE, ss);
               launch_update_matrices(ss, r0, r1, rs, flow_prev ? flow_prev + (size_t)s0 * fc_stride : nullptr, fc_stride, pw, ph, mul, gs, l.w, l.h,
                                      w.Ma + m_off, 5 * n0); }
-            sweeps_plain(c, ss, K_ITER_COARSE, w.Ma + m_off, w.Mb + m_off, r0, r1, rs, gs, l, fdst + (size_t)s0 * fstride, fstride);
+            sweeps_plain(c, ss, K_ITER_COARSE, w.Ma + m_off, w.Mb + m_off, r0, r1, rs, gs, l, fdst + (size_t)s0 * fstride, fstride, true);
         }
         prof_close_stream(c, c->pair_stream); prof_close_stream(c, st);
         HIPCHK(hipEventRecord(c->pif_join, c->pair_stream));

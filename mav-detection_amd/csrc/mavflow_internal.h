@@ -71,7 +71,8 @@ void launch_update_matrices_flow(hipStream_t st, const float* R0, const float* R
 void launch_blur_iter(hipStream_t st, const float* M_in, float* M_out, size_t M_stride, const float* R0, const float* R1,
                       size_t R_stride, int G, int w, int h, int winsize, int do_update, int store_flow, float* flow, size_t f_stride,
                       int ty0 = 0, int ty1 = -1 /* tile rows [ty0, ty1) of 16 pixel rows; ty1 < 0 = the whole layer */,
-                      int strip = 0 /* width in tiles of the tile order's column strips; 0 = automatic */);
+                      int strip = 0 /* width in tiles of the tile order's column strips; 0 = automatic */,
+                      bool write_through = false /* M' through sc1 stores: see k_blur_iter_fast */);
 int blur_iter_tile_rows(int h);                 // 16-pixel tile rows of a layer of height h
 // band launches (ty0 / ty1) are honoured only by the fast sweep kernel: true when launch_blur_iter will take it for these operands
 bool blur_iter_bands_ok(int w, int winsize, size_t M_stride, size_t R_stride, size_t f_stride, const void* M_in, const void* M_out,

@@ -353,7 +353,7 @@ def test_options_are_reported_and_validated(mav):
         assert info["layers"][0]["sweeps"].startswith("two pairs in flight") and info["layers"][0]["bands"] == 2
         assert info["layers"][1]["blur"] == "fused" and info["layers"][1]["pairs_per_launch"] == 4
         for name, v in (("band_mb", 40), ("coarse_half", 3), ("strip", 20), ("phi_yloop", 4), ("phi_screen", 0), ("share_m", 0),
-                        ("coarse_cache_mb", 100), ("bands", 3), ("group_fine", 2), ("small_batch", 0)):
+                        ("coarse_cache_mb", 100), ("bands", 3), ("group_fine", 2), ("small_batch", 0), ("sweep_write_through", 1)):
             c.set_option(name, v)
             assert c.get_option(name) == v
             assert c.schedule_info(64)[name] == v
@@ -441,6 +441,9 @@ def test_two_pairs_in_flight_give_the_same_flow(mav, size, batch, group):
         for key in ("flow", "mask_fixed", "mask_dyn"):
             assert np.array_equal(two[key], chain[key]), key
         assert two["results"].tobytes() == chain["results"].tobytes()
+        for wt in (0, 1, -1):                        # the sweeps' M' through plain or write-through (sc1) stores: the same values either way
+            c.set_option("sweep_write_through", wt)
+            assert np.array_equal(c.farneback(prev, nxt), ref), wt
         # the profile's interval union: launches of one class overlap, the busy time stays below their sum
         c.profile_enable(True)
         c.farneback(prev, nxt)
