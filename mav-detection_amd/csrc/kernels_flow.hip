@@ -818,7 +818,7 @@ static __device__ __forceinline__ void update_core(const float q[5], const float
                                                    int x, int y, float dx, float dy, float out[5])
 {
     // Every multiply-add below is spelled out (fmaf) and contraction is off for the rest: the bits must not depend on which kernel
-    // (or which template instantiation of one) the function is inlined into -- under the file's default -ffp-contract=fast two
+    // (or which template instantiation of one) the function is inlined into -- under -ffp-contract=fast (this file's setting until round 3) two
     // instantiations of the sweep kernel that differed in a store instruction fused `a*b + c*d` differently and their flows drifted
     // apart by up to 8e-4 px over twenty sweeps.  update_finish() below is the same arithmetic on values already gathered.
 #pragma clang fp contract(off)
