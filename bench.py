@@ -28,7 +28,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s 
 ITER_BYTES_UPDATE = 88           # SURVEY 8d's model, per pixel per sweep: read M 20 + R0 20 + R1 20, write M' 20 + flow 8
 ITER_BYTES_MOVED = 80            # what the kernel has to move: the flow of an updating sweep is consumed inside the kernel (store_flow = 0)
 ITER_BYTES_LAST = 28             # last sweep of a layer: read M 20, write flow 8
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 
 
 def b_alg_per_pair(layers, W, H, iters):
@@ -152,7 +152,127 @@ def verify_last_step(ctx, prev, nxt, samples, res, mf_buf, md_buf, pairs, levels
                             "against": "cv2" if kind == "reference" else "oracle restatement (cv2 absent)", "pairs": len(pairs)}}
 
 
-def run_config_leg(name, W, H, B, levels, calls, pairs_to_check, verify=True):
+def equal_plain_schedule(ctx, run_batch, d_res, d_mf, d_md, B, W, H):
+    """EVERY pair of the batch the timed loop just computed against the same batch re-run in the plain schedule (one stream, one pair
+    after the other: the form the parity tests check against the oracle): records, both masks and the whole flow must be identical.
+    Returns (all equal, pairs with identical flow, differing pairs)."""
+    import zlib
+    import numpy as np
+    from mavflow import _lib
+    rec = _lib.RESULT_DTYPE.itemsize
+
+    def digest():
+        return (d_res.download(np.uint8, (B * rec,)).tobytes(), zlib.crc32(d_mf.download(np.uint8, (B * W * H,))),
+                zlib.crc32(d_md.download(np.uint8, (B * W * H,))), [zlib.crc32(ctx.last_flow(b)) for b in range(B)])
+    timed = digest()
+    saved = ctx.get_option("pairs_in_flight")
+    ctx.set_option("pairs_in_flight", 1)
+    run_batch()
+    ctx.sync()
+    plain = digest()
+    ctx.set_option("pairs_in_flight", saved)
+    same = [b for b in range(B) if timed[3][b] == plain[3][b]]
+    ok = bool(timed[:3] == plain[:3] and len(same) == B)
+    differing = sorted(set(range(B)) - set(same)) if not ok else []
+    return ok, len(same), (differing if differing or ok else [-1])
+
+
+def host_enqueue_ms(ctx, step, reps=7):
+    """Host time of ENQUEUEING one step: the wall time of the call(s) of one step issued into an idle queue (sync before, clock stopped
+    when the last call returns, before any sync), median of `reps`.  What one host thread per rank has to sustain."""
+    ts = []
+    for _ in range(reps):
+        ctx.sync()
+        t0 = time.perf_counter()
+        step()
+        ts.append(1e3 * (time.perf_counter() - t0))
+        ctx.sync()
+    return sorted(ts)[len(ts) // 2]
+
+
+def traffic_record(want):
+    """HBM-side request bytes of the sweep launches of one step from the committed PMC record that matches this build, shape, batch and
+    schedule (profiles/<round>/traffic*.json, written by tools/pmc_passes.sh + tools/make_traffic.py): (bytes per launch or None, source)."""
+    pdir = os.path.join(ROOT, "profiles", PROFILE_ROUND)
+    why = []
+    for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if not (name.startswith("traffic") and name.endswith(".json")):
+            continue
+        rec_t = json.load(open(os.path.join(pdir, name)))
+        have = {k: rec_t.get(k) for k in want}
+        if have == want:
+            return (int(rec_t["hbm_bytes_sweeps_per_step"] / max(want["launches"], 1)),
+                    f"profiles/{PROFILE_ROUND}/{name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build, shape, batch and "
+                    f"schedule (memory-side request bytes: Infinity-Cache hits included, so not DRAM bytes); not measured by this run")
+        why.append(f"{name}: " + ", ".join(f"{k} {have[k]} != {want[k]}" for k in want if have[k] != want[k]))
+    return None, ("no committed PMC record matches this build / shape (" + "; ".join(why) + "): null" if why else "no PMC record committed: null")
+
+
+def sweep_roofline(ctx, run_batch, B, layers, W, H, levels, schedule, step_ms, ceil=None):
+    """Roofline of the dominant kernel (the sweeps) for the workload run_batch() enqueues, measured live with HIP events in two extra
+    passes outside any timed region: (1) events around every launch -> per-class sums, launch counts, avg launch duration (what
+    rocprofv3 --kernel-trace --stats reports per dispatch); (2) events around every RUN of launches of one class on a stream (a tenth
+    of the events, so the two streams overlap as in the timed loop) -> the union of the intervals in which a sweep launch runs."""
+    ctx.profile_enable(True)
+    run_batch()
+    prof = ctx.profile_get()
+    busy_per_launch_events = ctx.profile_busy("blur_iter", "blur_iter_coarse")
+    ctx.profile_enable(False)
+    ctx.profile_enable(2)
+    run_batch()
+    busy_ms = ctx.profile_busy("blur_iter", "blur_iter_coarse")
+    busy_all_ms = ctx.profile_busy(*prof.keys())        # time during which ANY kernel of the step was running (both streams)
+    ctx.profile_enable(False)
+    sum_ms = prof["blur_iter"][0] + prof.get("blur_iter_coarse", (0.0, 0))[0]
+    launches = prof["blur_iter"][1] + prof.get("blur_iter_coarse", (0, 0))[1]
+    iters = ctx.fb.iterations
+    npx_step = B * sum(w * h for (w, h) in layers)
+    bytes_moved = npx_step * ((iters - 1) * ITER_BYTES_MOVED + ITER_BYTES_LAST)
+    bytes_survey = npx_step * ((iters - 1) * ITER_BYTES_UPDATE + ITER_BYTES_LAST)
+    # Two pairs are in flight on two streams (the library's default schedule): sweep launches overlap pairwise, so the SUM of their
+    # durations exceeds the wall time.  The rate is quoted on the time during which the kernel was running at all -- the union of
+    # the launches' intervals; avg_launch_ms stays the per-launch figure rocprofv3 reports (tools/trace_union.py computes the same
+    # union from a rocprofv3 kernel trace).
+    achieved = bytes_moved / (busy_ms * 1e-3) / 1e9
+    achieved_survey = bytes_survey / (busy_ms * 1e-3) / 1e9
+    if ceil is None:
+        ceil = measured_ceilings(ctx)
+    # HBM bytes from the PMC counters: collected by tools/pmc_passes.sh in separate rocprofv3 --pmc runs of THIS workload, corrected
+    # as the microarchitecture guide prescribes, committed under profiles/ with the hash of the sources and schedule they were
+    # measured on.  Per launch, like `achieved`.  null unless the record matches this build, shape, batch and schedule.
+    traffic, traffic_source = traffic_record({"source_hash": source_hash(schedule), "width": W, "height": H, "batch": B, "levels": levels,
+                                              "launches": launches})
+    return {"bound": "hbm", "served_by": "infinity_cache", "kernel": "k_blur_iter_fast (all sweep launches of a step)",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "achieved_is": "effective algorithmic bandwidth = bytes the sweeps have to move (80 B/px per updating sweep: M, R0, R1 in, M' out -- "
+                           "the flow of all but a layer's last sweep never leaves the kernel; 28 B/px for the last) / time during which at least one "
+                           "sweep launch runs.  The schedule keeps every pair's band of M / R0 / R1 inside the 256 MB Infinity Cache between "
+                           "sweeps, so most of these bytes are served by the cache: this is NOT a DRAM rate, and `frac` compares it with the "
+                           "8 TB/s HBM spec only because that is the contract's denominator",
+            "achieved_survey_88B_model": round(achieved_survey, 1), "frac_survey_88B_model": round(achieved_survey / HBM_PEAK_GBS, 4),
+            "measured_ceiling": ceil,
+            "frac_of_measured_ceiling": round(achieved / max(ceil["infinity_cache_GBs"], 1e-9), 4),
+            "traffic": traffic, "traffic_source": traffic_source,
+            "avg_launch_ms": round(sum_ms / max(launches, 1), 4), "launches_per_step": launches,
+            "kernel_launches_per_step_all_classes": int(sum(v[1] for v in prof.values())),
+            "kernel_busy_ms": round(busy_ms, 3), "kernel_busy_ms_with_per_launch_events": round(busy_per_launch_events, 3),
+            "sum_of_launch_ms": round(sum_ms, 3),
+            "launches_in_flight": round(sum_ms / max(busy_per_launch_events, 1e-9), 2),
+            "note": "two pairs are in flight on two streams: sweep launches overlap, `achieved` = bytes of all sweep launches / kernel_busy_ms "
+                    "(union of the intervals in which the kernel runs, HIP events around every run of launches on each stream); avg_launch_ms / "
+                    "sum_of_launch_ms come from a pass with events around every launch, whose sum exceeds the step by design; the same union from a "
+                    f"rocprofv3 kernel trace: profiles/{PROFILE_ROUND}/sweep_busy_*.txt",
+            "alg_bytes_per_launch_avg": int(bytes_moved / max(launches, 1)),
+            "alg_bytes_per_launch_avg_survey_88B_model": int(bytes_survey / max(launches, 1)),
+            "kernel_share_of_step": round(busy_ms / step_ms, 3),
+            "device_busy_ms": round(busy_all_ms, 3),
+            "device_busy_note": "union of ALL kernel classes' intervals in the one-step pass with HIP events around runs of launches (no tracer: "
+                                "under rocprofv3 the host side of the launches becomes the bottleneck and idle gaps appear that the untraced "
+                                "run does not have); step time minus this = time in which nothing runs on the device",
+            "all_kernels_ms": {k: round(v[0], 3) for k, v in prof.items()}}
+
+
+def run_config_leg(name, W, H, B, levels, calls, pairs_to_check, verify=True, ceil=None):
     """One more BASELINE configuration through mav_process_batch_dev in a context of its own (never `value`): `calls` back-to-back
     calls with the frames resident, HIP-event time on the context's stream and wall time; then the last call's outputs of
     `pairs_to_check` against the oracle.  Returns the record for the bench line's "configs" object."""
@@ -197,6 +317,15 @@ def run_config_leg(name, W, H, B, levels, calls, pairs_to_check, verify=True):
         res = d_res.download(_lib.RESULT_DTYPE, (B,))
         v = verify_last_step(ctx, prev, nxt, samples, res, d_mf, d_md, pairs_to_check, levels)
         out.update({"verified_pairs": v["verified_pairs"], "failed_pairs": v["failed_pairs"], "flow_epe_px": v["flow_epe_px"]})
+        ok, n_same, differing = equal_plain_schedule(ctx, call, d_res, d_mf, d_md, B, W, H)
+        out["all_pairs_equal_plain_schedule"] = ok
+        out["pairs_with_identical_flow_in_plain_schedule"] = n_same
+        if not ok:
+            out["failed_pairs"] = sorted(set(out["failed_pairs"]) | set(differing))
+    # the dominant kernel of THIS configuration, untraced (same two passes as the headline's roofline block), and the host side
+    out["host_enqueue_ms_per_call"] = round(host_enqueue_ms(ctx, call), 4)
+    out["roofline"] = sweep_roofline(ctx, call, B, layers, W, H, levels, out["schedule"], ev_ms / calls, ceil)
+    out["host_enqueue_share_of_call"] = round(out["host_enqueue_ms_per_call"] / (ev_ms / calls), 3)
     ctx.close()
     return out
 
@@ -331,6 +460,7 @@ def main():
     ctx.timer_start()
     for _ in range(args.steps):
         step()
+    enq_loop = time.perf_counter() - t0               # every step is enqueued (includes any back-pressure of a full queue); nothing synchronised yet
     ev_ms = ctx.timer_stop()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -347,26 +477,12 @@ def main():
         assert allrec[rank * B:(rank + 1) * B].tobytes() == res_last.tobytes(), "all-gathered records differ from the local ones"
     if rank == 0 and not args.no_verify:
         verification = verify_last_step(ctx, prev, nxt, samples, res_last, d_mf, d_md, sorted({0, B - 1}), args.levels)
-        # ... and EVERY pair of the timed step against the same batch re-run in the plain schedule (one stream, one pair after the other: the form the parity tests check against the oracle): records, both masks and the whole flow must be identical
-        import zlib
-
-        def digest():
-            return (d_res.download(np.uint8, (B * rec,)).tobytes(), zlib.crc32(d_mf.download(np.uint8, (B * W * H,))),
-                    zlib.crc32(d_md.download(np.uint8, (B * W * H,))), [zlib.crc32(ctx.last_flow(b)) for b in range(B)])
-        timed = digest()
-        saved = {k: ctx.get_option(k) for k in ("pairs_in_flight",)}
-        ctx.set_option("pairs_in_flight", 1)
-        run_batch()
-        ctx.sync()
-        plain = digest()
-        for k, v in saved.items():
-            ctx.set_option(k, v)
-        same = [b for b in range(B) if timed[3][b] == plain[3][b]]
-        verification["all_pairs_equal_plain_schedule"] = bool(timed[:3] == plain[:3] and len(same) == B)
-        verification["pairs_with_identical_flow_in_plain_schedule"] = len(same)
-        if not verification["all_pairs_equal_plain_schedule"]:
-            differing = set(range(B)) - set(same)
-            verification["failed_pairs"] = sorted(set(verification["failed_pairs"]) | (differing if differing else {-1}))
+        # ... and EVERY pair of the timed step against the same batch re-run in the plain schedule
+        ok, n_same, differing = equal_plain_schedule(ctx, run_batch, d_res, d_mf, d_md, B, W, H)
+        verification["all_pairs_equal_plain_schedule"] = ok
+        verification["pairs_with_identical_flow_in_plain_schedule"] = n_same
+        if not ok:
+            verification["failed_pairs"] = sorted(set(verification["failed_pairs"]) | set(differing))
 
     # ---- PCIe-inclusive rates (never `value`).  (1) naive: the two u8 frame stacks uploaded synchronously from pageable memory
     #      inside the loop; (2) pipelined: pinned memory, uploads on the context's copy stream into a second buffer set while
@@ -425,89 +541,21 @@ def main():
         for d in (d_seq, d_p2, d_n2):
             d.free()
 
-    # ---- roofline of the dominant kernel (separate pass, HIP events around every launch on the context's stream) ----
+    # ---- roofline of the dominant kernel (separate passes, HIP events on the streams the launches go to) and the host side of a step ----
     roofline = None
+    ceil = None
+    enqueue_ms = None
     if rank == 0 and not args.no_profile:
-        ctx.profile_enable(True)
-        run_batch()
-        prof = ctx.profile_get()
-        busy_per_launch_events = ctx.profile_busy("blur_iter", "blur_iter_coarse")
-        ctx.profile_enable(False)
-        # second pass for the busy time: events around every RUN of sweep launches on a stream only (a tenth of the events), so that
-        # the two streams overlap as they do in the timed loop
-        ctx.profile_enable(2)
-        run_batch()
-        busy_ms = ctx.profile_busy("blur_iter", "blur_iter_coarse")
-        busy_all_ms = ctx.profile_busy(*prof.keys())        # time during which ANY kernel of the step was running (both streams)
-        ctx.profile_enable(False)
-        sum_ms = prof["blur_iter"][0] + prof.get("blur_iter_coarse", (0.0, 0))[0]
-        launches = prof["blur_iter"][1] + prof.get("blur_iter_coarse", (0, 0))[1]
-        iters = ctx.fb.iterations
-        npx_step = B * sum(w * h for (w, h) in layers)
-        bytes_moved = npx_step * ((iters - 1) * ITER_BYTES_MOVED + ITER_BYTES_LAST)
-        bytes_survey = npx_step * ((iters - 1) * ITER_BYTES_UPDATE + ITER_BYTES_LAST)
-        # Two pairs are in flight on two streams (the library's default schedule): sweep launches overlap pairwise, so the SUM of their
-        # durations exceeds the wall time.  The rate is quoted on the time during which the kernel was running at all -- the union of
-        # the launches' intervals (HIP events around every run of launches on the stream they go to); avg_launch_ms stays the
-        # per-launch figure rocprofv3 reports (tools/trace_union.py computes the same union from a rocprofv3 kernel trace).
-        ms = busy_ms
-        achieved = bytes_moved / (ms * 1e-3) / 1e9
-        achieved_survey = bytes_survey / (ms * 1e-3) / 1e9
+        enqueue_ms = host_enqueue_ms(ctx, step)
         ceil = measured_ceilings(ctx)
-        # HBM bytes from the PMC counters: collected by tools/pmc_passes.sh in separate rocprofv3 --pmc runs of THIS command,
-        # corrected as the microarchitecture guide prescribes, committed under profiles/ with the hash of the sources and schedule
-        # they were measured on.  Per launch, like `achieved`.  null unless the record matches this build, shape, batch and schedule.
-        traffic, traffic_source = None, None
-        want = {"source_hash": source_hash(schedule), "width": W, "height": H, "batch": B, "levels": args.levels, "launches": launches}
-        pdir = os.path.join(ROOT, "profiles", PROFILE_ROUND)
-        why = []
-        for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
-            if not (name.startswith("traffic") and name.endswith(".json")):
-                continue
-            rec_t = json.load(open(os.path.join(pdir, name)))
-            have = {k: rec_t.get(k) for k in want}
-            if have == want:
-                traffic = int(rec_t["hbm_bytes_sweeps_per_step"] / max(launches, 1))
-                traffic_source = (f"profiles/{PROFILE_ROUND}/{name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build, shape, batch and "
-                                  f"schedule (memory-side request bytes: Infinity-Cache hits included, so not DRAM bytes); not measured by this run")
-                break
-            why.append(f"{name}: " + ", ".join(f"{k} {have[k]} != {want[k]}" for k in want if have[k] != want[k]))
-        if traffic is None:
-            traffic_source = "no committed PMC record matches this build / shape (" + "; ".join(why) + "): null" if why else "no PMC record committed: null"
-        roofline = {"bound": "hbm", "served_by": "infinity_cache", "kernel": "k_blur_iter_fast (all sweep launches of a step)",
-                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "achieved_is": "effective algorithmic bandwidth = bytes the sweeps have to move (80 B/px per updating sweep: M, R0, R1 in, M' out -- "
-                                   "the flow of all but a layer's last sweep never leaves the kernel; 28 B/px for the last) / time during which at least one "
-                                   "sweep launch runs.  The schedule keeps every pair's band of M / R0 / R1 inside the 256 MB Infinity Cache between "
-                                   "sweeps, so most of these bytes are served by the cache: this is NOT a DRAM rate, and `frac` compares it with the "
-                                   "8 TB/s HBM spec only because that is the contract's denominator",
-                    "achieved_survey_88B_model": round(achieved_survey, 1), "frac_survey_88B_model": round(achieved_survey / HBM_PEAK_GBS, 4),
-                    "measured_ceiling": ceil,
-                    "frac_of_measured_ceiling": round(achieved / max(ceil["infinity_cache_GBs"], 1e-9), 4),
-                    "traffic": traffic, "traffic_source": traffic_source,
-                    "avg_launch_ms": round(sum_ms / max(launches, 1), 4), "launches_per_step": launches,
-                    "kernel_busy_ms": round(busy_ms, 3), "kernel_busy_ms_with_per_launch_events": round(busy_per_launch_events, 3),
-                    "sum_of_launch_ms": round(sum_ms, 3),
-                    "launches_in_flight": round(sum_ms / max(busy_per_launch_events, 1e-9), 2),
-                    "note": "two pairs are in flight on two streams: sweep launches overlap, `achieved` = bytes of all sweep launches / kernel_busy_ms "
-                            "(union of the intervals in which the kernel runs, HIP events around every run of launches on each stream); avg_launch_ms / "
-                            "sum_of_launch_ms come from a pass with events around every launch, whose sum exceeds the step by design; the same union from a "
-                            f"rocprofv3 kernel trace: profiles/{PROFILE_ROUND}/sweep_busy_*.txt",
-                    "alg_bytes_per_launch_avg": int(bytes_moved / max(launches, 1)),
-                    "alg_bytes_per_launch_avg_survey_88B_model": int(bytes_survey / max(launches, 1)),
-                    "kernel_share_of_step": round(ms / (1e3 * elapsed / args.steps), 3),
-                    "device_busy_ms": round(busy_all_ms, 3),
-                    "device_busy_note": "union of ALL kernel classes' intervals in the one-step pass with HIP events around runs of launches (no tracer: "
-                                        "under rocprofv3 the host side of the ~1 700 launches per step becomes the bottleneck and idle gaps appear "
-                                        "that the untraced run does not have); step time minus this = time in which nothing runs on the device",
-                    "all_kernels_ms": {k: round(v[0], 3) for k, v in prof.items()}}
+        roofline = sweep_roofline(ctx, run_batch, B, layers, W, H, args.levels, schedule, 1e3 * elapsed / args.steps, ceil)
 
     # ---- the other BASELINE configurations one GPU can hold (never `value`; outside the headline's timed region) ----
     configs = None
     if rank == 0 and world == 1 and not args.no_configs and (W, H, args.levels) == (1920, 1080, 1):
         d_prev.free(); d_next.free(); d_mf.free(); d_md.free()         # (the headline's buffers are no longer needed)
-        configs = {"C2": run_config_leg("C2", 1280, 720, 1, 1, 300, [0], verify=not args.no_verify),
-                   "C5_share": run_config_leg("C5_share", 3840, 2160, 16, 5, 10, [0, 15], verify=not args.no_verify)}
+        configs = {"C2": run_config_leg("C2", 1280, 720, 1, 1, 300, [0], verify=not args.no_verify, ceil=ceil),
+                   "C5_share": run_config_leg("C5_share", 3840, 2160, 16, 5, 10, [0, 15], verify=not args.no_verify, ceil=ceil)}
         configs["C5_share"]["note"] = "per-GPU share of BASELINE config 5 (batch 128 across 8 GPUs); its CPU baseline (73 s) is not repeated here"
 
     failed = False
@@ -529,6 +577,13 @@ def main():
                "pipeline_frac_of_8TBs": round(value / world * balg / (HBM_PEAK_GBS * 1e9), 4),
                "pipeline_frac_is": "whole-path algorithmic bytes per pair (SURVEY 8d) x pairs/s / 8 TB/s: an effective rate, partly served by the Infinity Cache",
                "source_hash": source_hash(schedule), "kernel_source_hash": source_hash()}
+        out["host_enqueue_ms_per_step_in_loop"] = round(1e3 * enq_loop / args.steps, 3)
+        if enqueue_ms is not None:
+            out["host_enqueue_ms_per_step"] = round(enqueue_ms, 3)
+            out["host_enqueue_share_of_step"] = round(enqueue_ms / (1e3 * elapsed / args.steps), 3)
+            out["host_enqueue_is"] = ("wall time of one step's mav_process_batch_dev (+ all-gather) call issued into an idle queue, median of 7 "
+                                      "(the *_in_loop figure is the timed loop's enqueue time / steps and includes queue back-pressure); "
+                                      "roofline.kernel_launches_per_step_all_classes launches + the fork / join events per step")
         if world > 1:
             out["scaling_note"] = "per-GPU work fixed (weak); efficiency is the driver's to compute from the per-N values"
         if h2d_ms:

@@ -68,7 +68,12 @@ void mav_foe_defaults(mav_foe_params*);
 void mav_thr_defaults(mav_thr_params*);
 
 /* ---- context ------------------------------------------------------------------------------------------- */
-/* One context per (device, W, H, max_batch); owns its stream, pyramid tables and workspace. */
+/* One context per (device, W, H, max_batch); owns its streams, pyramid tables and -- from the first call that computes flow on --
+ * the Farneback workspace (174 MB per 1080p slot, 16 slots by default): a context used only for mav_bbox / mav_tpr_fpr_counts /
+ * mav_phi_mask / mav_detect / the window search holds a few KB plus the staging blocks of its calls.
+ * Size bound: max_batch <= 65535 and max_batch * W * H <= 2^30 pixels (1920x1080 x 512 and 3840x2160 x 128, the global batches of
+ * BASELINE configs 4 and 5, are 1 % under it): MAV_ERR_ARG above, so that no per-batch element count leaves 32 bits. */
+#define MAV_MAX_BATCH_PIXELS ((size_t)1 << 30)
 int mav_create(mav_ctx** out, int device, int W, int H, int max_batch, const mav_fb_params* fb /* NULL = defaults */);
 int mav_destroy(mav_ctx*);
 const char* mav_last_error(void); /* thread-local, never NULL */
@@ -102,6 +107,10 @@ int mav_get_option(mav_ctx*, const char* name, long* value);
  * whether the small-batch schedule applies and, per layer, the blur form and how the sweeps run (pairs per launch, bands).
  * bench.py prints it into its record and hashes it together with the kernel sources. */
 int mav_schedule_info(mav_ctx*, int batch, char* buf, size_t cap);
+/* Device memory: free / total bytes of the context's GPU (hipMemGetInfo), the bytes this context holds in all (workspace, flow
+ * workspace, detection scratch, staging blocks of the host-pointer calls, window-search buffers) and the Farneback workspace alone
+ * (0 until a call computes flow).  Any pointer may be NULL. */
+int mav_mem_info(mav_ctx*, size_t* dev_free, size_t* dev_total, size_t* ctx_bytes, size_t* workspace_bytes);
 int mav_num_layers(const mav_ctx*);
 int mav_layer_dims(const mav_ctx*, int k, int* w, int* h, int* ksize, double* sigma);
 

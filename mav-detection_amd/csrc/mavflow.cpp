@@ -230,6 +230,8 @@ struct mav_ctx {
     bool phi_screen = true;          // "phi_screen": the float32 screen in front of the exact phi / threshold arithmetic
     int phi_yloop = 0;               // "phi_yloop": 16-row blocks per workgroup of the phi kernel (0 = automatic)
     size_t htmp_stride = 0;
+    bool ws_ready = false;         // the Farneback workspace exists (ensure_workspace: allocated by the first call that computes flow)
+    size_t ws_bytes = 0;           // its size
     float* flow_ws = nullptr;      // lazily allocated (max_batch) when the caller does not want the flow
     // detection scratch (max_batch)
     FoeScratch foe_sc{nullptr, nullptr, nullptr};
@@ -303,6 +305,12 @@ static void free_layer(Layer& l)
     l.g = nullptr;
 }
 
+// Pairs of the largest group the small-group schedule can take (is_small_group) when the context runs groups of `group` pairs.
+static int small_group_cap(const mav_ctx* c, int group)
+{
+    size_t sg = c->c_total ? ((size_t)c->small_batch_mb << 20) / (c->n0 * 80) : 0;
+    return (int)(sg > (size_t)group ? (size_t)group : sg);
+}
 // Workspace for `group` slots.  The new buffers are allocated in full before the old ones are released: when an allocation fails the
 // context keeps its previous group and stays usable (the caller sees MAV_ERR_OOM).
 static int alloc_group(mav_ctx* c, int group)
@@ -312,11 +320,11 @@ static int alloc_group(mav_ctx* c, int group)
     // Htmp holds g + 1 (the two-pass blur never runs over more frames per launch)
     enum { NB = 9 };
     // Ic / Rc: for the largest group the small-group schedule can take (is_small_group), 2 g frames of every coarse layer
-    size_t sg = c->c_total ? ((size_t)c->small_batch_mb << 20) / (c->n0 * 80) : 0;
-    if (sg > g) sg = g;
+    const size_t sg = (size_t)small_group_cap(c, group);
     const size_t elems[NB] = {c->n0 * 2 * g, 10 * c->n0 * g, 5 * c->n0 * g, 5 * c->n0 * g, nc * g, nc * g, c->htmp_stride * (g + 1),
                               sg ? 2 * sg * c->c_total : 1, sg ? 10 * sg * c->c_total : 1};
     float* fresh[NB] = {nullptr};
+    size_t total = 0;
     for (int i = 0; i < NB; i++) {
         const hipError_t e = hipMalloc(&fresh[i], sizeof(float) * elems[i]);
         if (e != hipSuccess) {
@@ -325,13 +333,23 @@ static int alloc_group(mav_ctx* c, int group)
             return fail(e == hipErrorOutOfMemory ? MAV_ERR_OOM : MAV_ERR_HIP, "workspace for group %d (%zu bytes for buffer %d): %s", group,
                         sizeof(float) * elems[i], i, hipGetErrorString(e));
         }
+        total += sizeof(float) * elems[i];
     }
     mav_ctx::WorkSet& w = c->ws;
     float** bufs[NB] = {&w.I, &w.R, &w.Ma, &w.Mb, &w.fc[0], &w.fc[1], &w.Htmp, &w.Ic, &w.Rc};
     for (int i = 0; i < NB; i++) { if (*bufs[i]) hipFree(*bufs[i]); *bufs[i] = fresh[i]; }
     c->group = group;
     c->small_g = (int)sg;
+    c->ws_ready = true;
+    c->ws_bytes = total;
     return MAV_OK;
+}
+// The Farneback workspace (174 MB per 1080p slot, 16 slots by default) belongs to the calls that compute flow: a context created for
+// mav_bbox / mav_tpr_fpr_counts / mav_phi_mask / mav_detect never pays for it (the reference's helpers are stateless free functions,
+// src/im_helpers.py:55-84,244-252).  Allocated by the first call that needs it, kept until mav_destroy.
+static int ensure_workspace(mav_ctx* c)
+{
+    return c->ws_ready ? MAV_OK : alloc_group(c, c->group);
 }
 
 static int sync_all_streams(mav_ctx* c)
@@ -371,6 +389,9 @@ extern "C" int mav_create(mav_ctx** out, int device, int W, int H, int max_batch
     mav_fb_params fb;
     if (fbp) fb = *fbp; else mav_fb_defaults(&fb);
     if (W < 1 || H < 1 || max_batch < 1) return fail(MAV_ERR_ARG, "mav_create: bad size W=%d H=%d max_batch=%d", W, H, max_batch);
+    if (max_batch > 65535 || (size_t)max_batch * (size_t)W * (size_t)H > MAV_MAX_BATCH_PIXELS)
+        return fail(MAV_ERR_ARG, "mav_create: max_batch %d x %dx%d exceeds the bound (max_batch <= 65535, max_batch * W * H <= %zu pixels)", max_batch,
+                    W, H, (size_t)MAV_MAX_BATCH_PIXELS);
     if (!(fb.pyr_scale > 0 && fb.pyr_scale < 1)) return fail(MAV_ERR_ARG, "pyr_scale must be in (0, 1), got %g", fb.pyr_scale);
     if (fb.levels < 0 || fb.winsize < 2 || fb.winsize > 64 || fb.iterations < 1 || fb.poly_n < 1 || fb.poly_n > MAV_MAX_POLY_N)
         return fail(MAV_ERR_ARG, "unsupported Farneback parameters (levels=%d winsize=%d iterations=%d poly_n=%d)", fb.levels,
@@ -391,7 +412,6 @@ extern "C" int mav_create(mav_ctx** out, int device, int W, int H, int max_batch
 
     mav_ctx* c = new mav_ctx();
     c->device = device; c->W = W; c->H = H; c->max_batch = max_batch; c->fb = fb;
-    int rc = MAV_OK;
     auto bail = [&](int code) { mav_destroy(c); return code; };
 #define HIPB(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fail(e_ == hipErrorOutOfMemory ? MAV_ERR_OOM : MAV_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); return bail(e_ == hipErrorOutOfMemory ? MAV_ERR_OOM : MAV_ERR_HIP); } } while (0)
     for (hipStream_t* st : {&c->stream, &c->copy_stream, &c->pair_stream}) HIPB(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
@@ -449,8 +469,8 @@ extern "C" int mav_create(mav_ctx** out, int device, int W, int H, int max_batch
         if (c->bands > 8) c->bands = 8;
     }
     c->bands_auto = c->bands;
-    rc = alloc_group(c, group);
-    if (rc != MAV_OK) return bail(rc);
+    c->group = group;                                   // the workspace itself comes with the first call that computes flow (ensure_workspace)
+    c->small_g = small_group_cap(c, group);
     const size_t B = (size_t)max_batch;
     HIPB(hipMalloc(&c->foe_dev, sizeof(double) * 2 * B));
     HIPB(hipMalloc(&c->box_acc, sizeof(int32_t) * 4 * B));
@@ -505,7 +525,9 @@ extern "C" int mav_set_option(mav_ctx* c, const char* name, long value)
         const int g = v > c->max_batch ? c->max_batch : v;
         HIPCHK(hipSetDevice(c->device));
         CHK(sync_all_streams(c));
-        return g == c->group ? MAV_OK : alloc_group(c, g);
+        if (g == c->group) return MAV_OK;
+        if (!c->ws_ready) { c->group = g; c->small_g = small_group_cap(c, g); return MAV_OK; }    // nothing allocated yet: the plan changes
+        return alloc_group(c, g);
     }
     if (!strcmp(name, "group_fine")) { c->group_fine = v; c->group_fine_set = true; }
     else if (!strcmp(name, "bands")) {          // 0 = back to automatic
@@ -531,6 +553,32 @@ extern "C" int mav_layer_dims(const mav_ctx* c, int k, int* w, int* h, int* ksiz
 {
     if (!c || k < 0 || k >= (int)c->layers.size()) return fail(MAV_ERR_ARG, "mav_layer_dims: bad layer %d", k);
     if (w) *w = c->layers[k].w; if (h) *h = c->layers[k].h; if (ksize) *ksize = c->layers[k].ksize; if (sigma) *sigma = c->layers[k].sigma;
+    return MAV_OK;
+}
+
+// Device memory: what the GPU has free / in total (hipMemGetInfo) and what THIS context holds -- the Farneback workspace (0 until a
+// call computes flow), the flow workspace, the detection scratch, the staging blocks of the host-pointer calls, the window-search buffers.
+extern "C" int mav_mem_info(mav_ctx* c, size_t* dev_free, size_t* dev_total, size_t* ctx_bytes, size_t* workspace_bytes)
+{
+    if (!c) return fail(MAV_ERR_ARG, "mav_mem_info: NULL context");
+    HIPCHK(hipSetDevice(c->device));
+    size_t fr = 0, tot = 0;
+    HIPCHK(hipMemGetInfo(&fr, &tot));
+    if (dev_free) *dev_free = fr;
+    if (dev_total) *dev_total = tot;
+    if (workspace_bytes) *workspace_bytes = c->ws_bytes;
+    if (ctx_bytes) {
+        const size_t B = (size_t)c->max_batch;
+        size_t n = c->ws_bytes + c->pyr_ws_bytes;
+        if (c->flow_ws) n += sizeof(float) * 2 * c->n0 * B;
+        if (c->sat) n += sizeof(unsigned long long) * (size_t)(c->W + 1) * (c->H + 1) * B;
+        if (c->foe_sc.cand) n += sizeof(double) * 2 * (size_t)c->foe_sc_n * B;
+        n += B * (sizeof(double) * 2 + sizeof(int32_t) * 4 + sizeof(unsigned long long) * 4 + sizeof(int) + sizeof(DerotParams) + sizeof(int) +
+                  sizeof(unsigned long long) + sizeof(unsigned) * 2);
+        for (const auto& l : c->layers) n += sizeof(float) * l.ksize;
+        for (const auto& b : c->scratch) n += b.cap;
+        *ctx_bytes = n;
+    }
     return MAV_OK;
 }
 
@@ -1047,6 +1095,7 @@ extern "C" int mav_farneback_dev(mav_ctx* c, const uint8_t* prev, const uint8_t*
     if (!c || !prev || !next || !flow) return fail(MAV_ERR_ARG, "mav_farneback: NULL argument");
     if (batch < 1 || batch > c->max_batch) return fail(MAV_ERR_ARG, "batch %d outside [1, %d]", batch, c->max_batch);
     HIPCHK(hipSetDevice(c->device));
+    CHK(ensure_workspace(c));
     // A frame SEQUENCE -- the caller's two batches are views of one run of batch + 1 consecutive frames, next = prev + one frame,
     // which is how a video goes through the reference's loop (src/farneback.py:76-80 with prevgray = the last call's frame) -- has
     // every inner frame in two pairs.  Each group then blurs and expands its g + 1 frames once instead of 2 g (same arithmetic per
@@ -1730,6 +1779,7 @@ static int stage_blur_resize(mav_ctx* c, const uint8_t* img, int k, bool two_pas
     const Layer* l;
     CHK(layer_of(c, k, &l));
     if (!img || !out) return fail(MAV_ERR_ARG, "mav_stage_blur_resize: NULL argument");
+    CHK(ensure_workspace(c));                           // (the two-pass form's scratch)
     const size_t n = (size_t)l->w * l->h;
     DevBuf di, dout;
     CHK(di.upload(c, img, c->n0)); CHK(dout.alloc(c, n * sizeof(float)));

@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.environ.get("MAVFLOW_SO", os.path.join(HERE, "libmavflow.so"))   # override: diagnostic builds only
+SO_PATH = os.path.join(HERE, "libmavflow.so")          # the one library the product loads; no environment override
 
 MAV_OK, MAV_ERR_ARG, MAV_ERR_HIP, MAV_ERR_OOM, MAV_ERR_STATE = 0, -1, -2, -3, -4
 
@@ -50,20 +50,25 @@ EXPORTS = [
     "mav_analyze_pyramid", "mav_pyramid_levels", "mav_pyramid_dims", "mav_optimize_window", "mav_stage_pyramid_level",
     "mav_detect", "mav_detect_dev", "mav_last_flow_dev", "mav_foe_dense_f32", "mav_phi_mask_f32", "mav_stage_coefficients",
     "mav_stage_phi_mask", "mav_last_masks_tpr_fpr", "mav_get_option", "mav_schedule_info", "mav_stage_blur_resize_two_pass",
-    "mav_membw_probe", "mav_runtime_info", "mav_upload_async_unordered",
+    "mav_membw_probe", "mav_runtime_info", "mav_upload_async_unordered", "mav_mem_info",
 ]
 
 _lib = None
 
 
-def load() -> C.CDLL:
-    """Load libmavflow.so (built in-tree by `make -C mav-detection_amd/csrc` / __graft_entry__.build())."""
+def load(path: str | None = None) -> C.CDLL:
+    """Load libmavflow.so (built in-tree by `make -C mav-detection_amd/csrc` / __graft_entry__.build()).
+    path: an explicit other build of the same ABI, given by a diagnostic tool BEFORE anything else loads the library
+    (tools/phase_stamps.py and its -DMAV_STAMPS build); the product never passes one."""
     global _lib
     if _lib is not None:
+        if path is not None and os.path.abspath(path) != _lib._name:
+            raise RuntimeError(f"libmavflow is already loaded from {_lib._name}")
         return _lib
-    if not os.path.exists(SO_PATH):
-        raise ImportError(f"{SO_PATH} is missing: build it with __graft_entry__.build(); there is no CPU fallback")
-    lib = C.CDLL(SO_PATH)
+    so = os.path.abspath(path) if path is not None else SO_PATH
+    if not os.path.exists(so):
+        raise ImportError(f"{so} is missing: build it with __graft_entry__.build(); there is no CPU fallback")
+    lib = C.CDLL(so)
     lib.mav_last_error.restype = C.c_char_p
     lib.mav_stream.restype = C.c_void_p
     lib.mav_last_flow_dev.restype = C.c_void_p
@@ -79,6 +84,7 @@ def load() -> C.CDLL:
     lib.mav_runtime_info.argtypes = [C.c_char_p, C.c_size_t]
     lib.mav_membw_probe.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
     lib.mav_num_layers.argtypes = [C.c_void_p]
+    lib.mav_mem_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_size_t)] * 4
     lib.mav_layer_dims.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4
     vp = C.c_void_p
     lib.mav_farneback.argtypes = [vp, vp, vp, C.c_int, vp]
@@ -320,6 +326,13 @@ class Context:
         buf = C.create_string_buffer(8192)
         check(self.lib.mav_schedule_info(self.h, int(batch), buf, len(buf)))
         return json.loads(buf.value.decode())
+
+    def mem_info(self) -> dict:
+        """Device memory in bytes: free / total of the GPU, what this context holds in all, and its Farneback workspace alone
+        (0 until a call computes flow)."""
+        v = [C.c_size_t() for _ in range(4)]
+        check(self.lib.mav_mem_info(self.h, *[C.byref(x) for x in v]))
+        return dict(zip(("dev_free", "dev_total", "ctx_bytes", "workspace_bytes"), (x.value for x in v)))
 
     def num_layers(self) -> int:
         return self.lib.mav_num_layers(self.h)

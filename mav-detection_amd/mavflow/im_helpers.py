@@ -11,16 +11,25 @@ import numpy as np
 from . import _lib
 from .utils import Rectangle
 
-_ctx_cache = {}
+_CTX_CACHE_SIZES = 2                 # frame sizes kept at one time
+_ctx_cache = {}                      # (W, H) -> Context, least recently used first (dicts keep insertion order)
 
 
 def _ctx(W: int, H: int, batch: int = 1) -> "_lib.Context":
-    """One cached context per frame size (the reference's helpers are free functions with no state)."""
+    """A cached context for this frame size.  The reference's helpers are free functions with no state (im_helpers.py:55-84,
+    244-252): the cache holds the contexts of the _CTX_CACHE_SIZES most recently used frame sizes and CLOSES what it drops -- a
+    replaced context (larger batch wanted) and the least recently used size.  Such contexts never compute flow, so each holds
+    only the staging blocks of its calls (no Farneback workspace: mav_create allocates none)."""
     key = (W, H)
-    c = _ctx_cache.get(key)
-    if c is None or c.max_batch < batch:
+    c = _ctx_cache.pop(key, None)
+    if c is not None and c.max_batch < batch:
+        c.close()
+        c = None
+    if c is None:
         c = _lib.Context(W, H, max(batch, 1))
-        _ctx_cache[key] = c
+    _ctx_cache[key] = c              # most recently used last
+    while len(_ctx_cache) > _CTX_CACHE_SIZES:
+        _ctx_cache.pop(next(iter(_ctx_cache))).close()
     return c
 
 

@@ -73,3 +73,23 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dp, f), errors="replace").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "farneback_oracle" not in src and "libfboracle" not in src, f
+
+
+def test_size_bound_is_an_argument_error(mav):
+    """max_batch * W * H above 2^30 pixels (include/mavflow.h: MAV_MAX_BATCH_PIXELS) is refused before anything touches a device."""
+    from mavflow import _lib
+    h = C.c_void_p()
+    lib = _lib.load()
+    for (W, H, B) in ((1920, 1080, 518), (3840, 2160, 130), (64, 48, 65536)):
+        assert lib.mav_create(C.byref(h), 0, W, H, B, None) == _lib.MAV_ERR_ARG, (W, H, B)
+        assert b"bound" in lib.mav_last_error()
+    txt = open(os.path.join(ROOT, "include", "mavflow.h")).read()
+    assert "MAV_MAX_BATCH_PIXELS ((size_t)1 << 30)" in txt
+    assert 1920 * 1080 * 512 <= 1 << 30 and 3840 * 2160 * 128 <= 1 << 30       # BASELINE configs 4 and 5 are inside it
+
+
+def test_no_environment_override_of_the_library_path(mav, monkeypatch):
+    from mavflow import _lib
+    src = open(_lib.__file__).read()
+    assert "os.environ" not in src and "getenv" not in src
+    assert _lib.SO_PATH.endswith(os.path.join("mavflow", "libmavflow.so"))

@@ -1,10 +1,11 @@
 """Diagnostic: where do the waves of the sweep kernel spend their cycles?  Needs the -DMAV_STAMPS build
-(`make -C mav-detection_amd/csrc diag` -> mav-detection_amd/mavflow/libmavflow_diag.bin); never used by the product."""
+(`make -C mav-detection_amd/csrc diag` -> mav-detection_amd/csrc/build_diag/libmavflow_diag.so); never used by the product.
+    python tools/phase_stamps.py [batch] [group_fine] [path of the diagnostic library]"""
 import ctypes as C, os, sys
 sys.path.insert(0, "mav-detection_amd")
-os.environ["MAVFLOW_SO"] = os.path.abspath("mav-detection_amd/mavflow/libmavflow_diag.bin")
 import numpy as np
 from mavflow import _lib, synth
+_lib.load(sys.argv[3] if len(sys.argv) > 3 else "mav-detection_amd/csrc/build_diag/libmavflow_diag.so")
 W, H, B = 1920, 1080, int(sys.argv[1]) if len(sys.argv) > 1 else 8
 gf = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 ctx = _lib.Context(W, H, B)
