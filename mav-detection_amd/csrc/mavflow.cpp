@@ -208,6 +208,14 @@ struct mav_ctx {
     } ws;
     std::vector<size_t> c_off, c_stride;      // per layer (index 0 unused); c_total = sum of the strides
     size_t c_total = 0;
+    // DEEP LAYERS (deep_layers): layers kd .. top, each at most 1/32 of the frame (layers 2 - 4 of the 4K / 5-layer preset), are
+    // latency-bound chains of tiny launches.  When a call has more than one group they run ONCE for up to deep_cap pairs of the call
+    // (all their images from one launch, all expansions from one launch, sweeps over all pairs) before the groups start; the groups
+    // then begin at layer kd - 1 with the deep flow as their coarser layer.  Buffers of their own, every layer in a compact region.
+    struct DeepSet { float *I = nullptr, *R = nullptr, *Ma = nullptr, *Mb = nullptr, *f[2] = {nullptr, nullptr}; } deep;
+    int kd = 0, deep_cap = 0;                 // kd = 0: no deep layer
+    bool deep_batch = true;                   // option "deep_batch"
+    bool coarse_bands = true;                 // option "coarse_bands": a coarse layer whose per-pair working set exceeds band_mb is swept like the finest one
     int small_g = 0;                          // pairs the Ic / Rc buffers were sized for (0: none)
     bool small_batch = true;                  // option "small_batch"
     int sweep_wt = -1;                        // option "sweep_write_through": -1 = in the two-stream schedules only (default), 0 / 1 = never / always
@@ -232,6 +240,7 @@ struct mav_ctx {
     size_t htmp_stride = 0;
     bool ws_ready = false;         // the Farneback workspace exists (ensure_workspace: allocated by the first call that computes flow)
     size_t ws_bytes = 0;           // its size
+    size_t deep_bytes = 0;
     float* flow_ws = nullptr;      // lazily allocated (max_batch) when the caller does not want the flow
     // detection scratch (max_batch)
     FoeScratch foe_sc{nullptr, nullptr, nullptr};
@@ -335,13 +344,30 @@ static int alloc_group(mav_ctx* c, int group)
         }
         total += sizeof(float) * elems[i];
     }
+    // the deep layers' work set does not depend on the group: allocated with the first workspace, kept across "group" changes
+    if (c->kd > 0 && !c->deep.I) {
+        const size_t D = (size_t)c->deep_cap, dt = c->c_total - c->c_off[c->kd], top = c->c_stride[c->kd];
+        const size_t de[6] = {2 * D * dt, 10 * D * dt, 5 * D * top, 5 * D * top, 2 * D * top, 2 * D * top};
+        float* d[6] = {nullptr};
+        for (int i = 0; i < 6; i++) {
+            const hipError_t e = hipMalloc(&d[i], sizeof(float) * de[i]);
+            if (e != hipSuccess) {
+                for (int j = 0; j < 6; j++) if (d[j]) hipFree(d[j]);
+                for (int j = 0; j < NB; j++) if (fresh[j]) hipFree(fresh[j]);
+                (void)hipGetLastError();
+                return fail(e == hipErrorOutOfMemory ? MAV_ERR_OOM : MAV_ERR_HIP, "deep-layer workspace (%zu bytes): %s", sizeof(float) * de[i], hipGetErrorString(e));
+            }
+            c->deep_bytes += sizeof(float) * de[i];
+        }
+        c->deep.I = d[0]; c->deep.R = d[1]; c->deep.Ma = d[2]; c->deep.Mb = d[3]; c->deep.f[0] = d[4]; c->deep.f[1] = d[5];
+    }
     mav_ctx::WorkSet& w = c->ws;
     float** bufs[NB] = {&w.I, &w.R, &w.Ma, &w.Mb, &w.fc[0], &w.fc[1], &w.Htmp, &w.Ic, &w.Rc};
     for (int i = 0; i < NB; i++) { if (*bufs[i]) hipFree(*bufs[i]); *bufs[i] = fresh[i]; }
     c->group = group;
     c->small_g = (int)sg;
     c->ws_ready = true;
-    c->ws_bytes = total;
+    c->ws_bytes = total + c->deep_bytes;
     return MAV_OK;
 }
 // The Farneback workspace (174 MB per 1080p slot, 16 slots by default) belongs to the calls that compute flow: a context created for
@@ -367,7 +393,7 @@ extern "C" int mav_destroy(mav_ctx* c)
     for (auto& l : c->layers) free_layer(l);
     {
         mav_ctx::WorkSet& w = c->ws;
-        void* wb[] = {w.I, w.R, w.Ma, w.Mb, w.fc[0], w.fc[1], w.Htmp, w.Ic, w.Rc};
+        void* wb[] = {w.I, w.R, w.Ma, w.Mb, w.fc[0], w.fc[1], w.Htmp, w.Ic, w.Rc, c->deep.I, c->deep.R, c->deep.Ma, c->deep.Mb, c->deep.f[0], c->deep.f[1]};
         for (void* b : wb) if (b) hipFree(b);
     }
     void* bufs[] = {c->flow_ws, c->foe_sc.cand, c->foe_sc.count, c->foe_sc.best_key, c->foe_sc.done, c->foe_dev, c->box_acc, c->u64_scratch,
@@ -454,6 +480,9 @@ extern "C" int mav_create(mav_ctx** out, int device, int W, int H, int max_batch
         c->c_off[k] = c->c_total;
         c->c_total += c->c_stride[k];
     }
+    for (int k = levels; k >= 2; k--)                   // deep layers: the top of the pyramid, every layer at most 1/32 of the frame
+        if ((size_t)c->layers[k].w * c->layers[k].h * 32 <= c->n0) c->kd = k; else break;
+    c->deep_cap = max_batch < 64 ? max_batch : 64;
     c->htmp_stride = (size_t)H * W;                    // any layer (even layer 0 when its fast form does not apply) fits
     // group: pairs per launch for everything but the finest layer's sweeps (see flow_group).
     // (1080p, 64 pairs: 27.0 - 27.5 ms with groups of 16 or 32, 27.8 - 28.1 with 8, 28.4 with 4 -- the batched blur / expansion
@@ -491,7 +520,8 @@ struct OptionDesc { const char* name; long lo, hi; };
 static const OptionDesc kOptions[] = {
     {"group", 1, 1 << 20}, {"group_fine", 0, 1 << 20}, {"bands", 0, 8}, {"pairs_in_flight", 1, 2}, {"band_mb", 8, 1 << 20},
     {"coarse_cache_mb", 0, 1 << 20}, {"coarse_half", 0, 1 << 20}, {"share_m", 0, 1}, {"share_frames", 0, 1}, {"strip", 0, 1 << 20},
-    {"phi_screen", 0, 1}, {"phi_yloop", 0, 1 << 20}, {"small_batch", 0, 1}, {"sweep_write_through", -1, 1},
+    {"phi_screen", 0, 1}, {"phi_yloop", 0, 1 << 20}, {"small_batch", 0, 1}, {"sweep_write_through", -1, 1}, {"deep_batch", 0, 1},
+    {"coarse_bands", 0, 1},
 };
 static long* option_slot(mav_ctx* c, const char* name, long* tmp)
 {
@@ -500,7 +530,7 @@ static long* option_slot(mav_ctx* c, const char* name, long* tmp)
         {"group", c->group}, {"group_fine", c->group_fine}, {"bands", c->bands}, {"pairs_in_flight", c->pairs_in_flight},
         {"band_mb", c->pif_band_mb}, {"coarse_cache_mb", c->coarse_cache_mb}, {"coarse_half", c->coarse_half}, {"share_m", c->share_m},
         {"share_frames", c->share_frames}, {"strip", c->strip}, {"phi_screen", c->phi_screen}, {"phi_yloop", c->phi_yloop},
-        {"small_batch", c->small_batch}, {"sweep_write_through", c->sweep_wt},
+        {"small_batch", c->small_batch}, {"sweep_write_through", c->sweep_wt}, {"deep_batch", c->deep_batch}, {"coarse_bands", c->coarse_bands},
     };
     for (auto& e : cur) if (!strcmp(e.n, name)) { *tmp = e.v; return tmp; }
     return nullptr;
@@ -545,6 +575,8 @@ extern "C" int mav_set_option(mav_ctx* c, const char* name, long value)
     else if (!strcmp(name, "phi_yloop")) c->phi_yloop = v;
     else if (!strcmp(name, "small_batch")) c->small_batch = v != 0;
     else if (!strcmp(name, "sweep_write_through")) c->sweep_wt = v;
+    else if (!strcmp(name, "deep_batch")) c->deep_batch = v != 0;
+    else if (!strcmp(name, "coarse_bands")) c->coarse_bands = v != 0;
     return MAV_OK;
 }
 
@@ -811,7 +843,13 @@ static SweepPlan plan_sweeps(const mav_ctx* c, int k, int g, bool bands_ok)
     // Infinity Cache when the first sweep reads them (measured -0.5 ms per 64 pairs; doing the same with the blur and the expansion
     // costs more in small launches than it returns)
     p.m_per_sub = p.sub < g;
-    if (k > 0 && c->pairs_in_flight == 2 && g >= 2) {
+    const size_t ws_pair = (size_t)l.w * l.h * 80, band_bytes = (size_t)c->pif_band_mb << 20;
+    // A COARSE layer whose per-pair working set exceeds a band (layer 1 of the 4K preset: 1536 x 864, 106 MB) is swept exactly like the
+    // finest one: pairs alternate between the two streams, each band-major, so that the two pairs in flight occupy 2 x <= 86 MB of the
+    // Infinity Cache instead of 2 x 106 MB (option "coarse_bands").
+    const bool big_coarse = k > 0 && c->coarse_bands && bands_ok && ws_pair > band_bytes && T / (I + 2) >= 2;
+    if (big_coarse) { p.sub = 1; p.m_per_sub = true; }
+    if (k > 0 && !big_coarse && c->pairs_in_flight == 2 && g >= 2) {
         // COARSE LAYERS with two sub-groups in flight: sub-groups of half the cache-sized count alternate between the compute stream
         // and pair_stream, each with its own M slots, for the same reason as the pairs of the finest layer below -- 25.5 - 25.6 vs
         // 26.0 - 26.6 ms per 64 pairs at 1080p with 4 + 4 instead of 8 pairs per launch (3 + 3: 25.7 - 25.8; 8 + 8: 26.4;
@@ -822,7 +860,7 @@ static SweepPlan plan_sweeps(const mav_ctx* c, int k, int g, bool bands_ok)
         if (2 * p.half > g) p.half = (g + 1) / 2;
         return p;
     }
-    if (k == 0 && c->pairs_in_flight == 2 && p.m_per_sub && p.sub == 1 && g >= 2) {
+    if ((k == 0 || big_coarse) && c->pairs_in_flight == 2 && p.m_per_sub && p.sub == 1 && g >= 2) {
         // TWO PAIRS IN FLIGHT (finest layer, one pair per launch).  Pair s of the group runs on stream s & 1 -- the compute stream
         // and pair_stream -- and ping-pongs M through slot s & 1.  The two streams never wait for each other inside the group
         // (different pairs: no dependency; one fork and one join event per group), so one stream's launches fill the kernel
@@ -832,8 +870,7 @@ static SweepPlan plan_sweeps(const mav_ctx* c, int k, int g, bool bands_ok)
         // (profiles/r02/ab_two_pairs*.log): 1080p 25.9 - 26.3 vs 27.1 - 27.4 ms per 64 pairs, 4K 28.7 vs 30.1 ms per 16 pairs; two full
         // pairs without bands 28.6 ms, three or four streams 27.9 - 28.1 ms.  Same tiles, same arithmetic as every other schedule:
         // bit-identical flow (tests/test_gpu_flow.py).
-        const size_t ws = (size_t)l.w * l.h * 80, band = (size_t)c->pif_band_mb << 20;
-        int J = c->bands_set ? c->bands : (int)((ws + band - 1) / band);
+        int J = (c->bands_set && k == 0) ? c->bands : (int)((ws_pair + band_bytes - 1) / band_bytes);
         const int Jmax = T / (I + 2);          // a band needs iterations + 2 tile rows (the skew must not reach the image top)
         if (J > Jmax) J = Jmax;
         if (J < 1) J = 1;
@@ -861,17 +898,16 @@ static SweepPlan plan_sweeps(const mav_ctx* c, int k, int g, bool bands_ok)
 // above have written into Ma (their odd sweeps end one whole tile row higher); the rows two neighbouring bands both need are
 // simply built twice, to the same values.
 struct BandUpdate { const float* flow_prev; size_t fc_stride; int pw, ph; float mul; };
-static void sweeps_band_major(mav_ctx* c, hipStream_t st, int kid, float* Ma, float* Mb, const float* r0, const float* r1, size_t rs, int gs,
+static void sweeps_band_major(mav_ctx* c, hipStream_t st, int kid, float* Ma, float* Mb, size_t ms, const float* r0, const float* r1, size_t rs, int gs,
                               int lw, int lh, int T, int J, float* fo, size_t fstride, const BandUpdate* upd = nullptr, bool two_streams = false)
 {
     const bool wt = c->sweep_wt < 0 ? two_streams : c->sweep_wt != 0;
-    const size_t n0 = c->n0;
     const int I = c->fb.iterations;
     for (int j = 0; j < J; j++) {
         const int a0 = (int)((long long)T * j / J), a1 = (int)((long long)T * (j + 1) / J);
         if (upd) {
             ProfScope ps(c, K_UPDATE, st);
-            launch_update_matrices(st, r0, r1, rs, upd->flow_prev, upd->fc_stride, upd->pw, upd->ph, upd->mul, gs, lw, lh, Ma, 5 * n0,
+            launch_update_matrices(st, r0, r1, rs, upd->flow_prev, upd->fc_stride, upd->pw, upd->ph, upd->mul, gs, lw, lh, Ma, ms,
                                    j == 0 ? 0 : a0 * 16 - 8, j == J - 1 ? lh : a1 * 16 + 8);
         }
         for (int it = 0; it < I; it++) {
@@ -880,37 +916,34 @@ static void sweeps_band_major(mav_ctx* c, hipStream_t st, int kid, float* Ma, fl
             if (ty0 < 0) ty0 = 0;
             if (ty1 <= ty0) continue;
             ProfScope ps(c, kid, st);
-            launch_blur_iter(st, (it & 1) ? Mb : Ma, (it & 1) ? Ma : Mb, 5 * n0, r0, r1, rs, gs, lw, lh, c->fb.winsize, update, !update, fo,
+            launch_blur_iter(st, (it & 1) ? Mb : Ma, (it & 1) ? Ma : Mb, ms, r0, r1, rs, gs, lw, lh, c->fb.winsize, update, !update, fo,
                              fstride, ty0, ty1, c->strip, wt);
         }
     }
 }
 
 // initial M + the `iterations` sweeps of gs pairs, sweep-major, on stream ss
-static void sweeps_plain(mav_ctx* c, hipStream_t ss, int kid, float* Min, float* Mout, const float* r0, const float* r1, size_t rs, int gs,
+static void sweeps_plain(mav_ctx* c, hipStream_t ss, int kid, float* Min, float* Mout, size_t ms, const float* r0, const float* r1, size_t rs, int gs,
                          const Layer& l, float* fo, size_t fstride, bool two_streams = false)
 {
-    const size_t n0 = c->n0;
     const bool wt = c->sweep_wt < 0 ? two_streams : c->sweep_wt != 0;
     for (int it = 0; it < c->fb.iterations; it++) {
         const int update = it < c->fb.iterations - 1;
         { ProfScope ps(c, kid, ss);
-          launch_blur_iter(ss, Min, Mout, 5 * n0, r0, r1, rs, gs, l.w, l.h, c->fb.winsize, update, !update, fo, fstride, 0, -1, c->strip, wt); }
+          launch_blur_iter(ss, Min, Mout, ms, r0, r1, rs, gs, l.w, l.h, c->fb.winsize, update, !update, fo, fstride, 0, -1, c->strip, wt); }
         if (update) { float* t = Min; Min = Mout; Mout = t; }
     }
 }
 
 // Initial M and the `iterations` sweeps of layer k for g pairs whose expansions lie at r0 / r1 (slot stride rs), starting on
-// stream st.  flow_prev = the coarser layer's flow (pw x ph, nullptr at the top layer); the layer's flow goes to fdst (slot stride
-// fstride).  On return everything has been joined back into st.
+// stream st.  flow_prev = the coarser layer's flow (pw x ph, slot stride fc_stride; nullptr at the top layer); the layer's flow goes to
+// fdst (slot stride fstride).  M ping-pongs through Ma / Mb (slot stride ms).  On return everything has been joined back into st.
 static int layer_sweeps(mav_ctx* c, hipStream_t st, int k, int g, const float* r0g, const float* r1g, size_t rs, const float* flow_prev,
-                        size_t fc_stride, int pw, int ph, float* fdst, size_t fstride)
+                        size_t fc_stride, int pw, int ph, float* fdst, size_t fstride, float* Ma, float* Mb, size_t ms)
 {
-    mav_ctx::WorkSet& w = c->ws;
-    const size_t n0 = c->n0;
     const Layer& l = c->layers[k];
     const float mul = (float)(1. / c->fb.pyr_scale);
-    const bool bands_ok = blur_iter_bands_ok(l.w, c->fb.winsize, 5 * n0, rs, fstride, w.Ma, w.Mb, r0g, r1g, fdst);
+    const bool bands_ok = blur_iter_bands_ok(l.w, c->fb.winsize, ms, rs, fstride, Ma, Mb, r0g, r1g, fdst);
     const SweepPlan p = plan_sweeps(c, k, g, bands_ok);
     const int kid = k == 0 ? K_ITER : K_ITER_COARSE;
     const int T = blur_iter_tile_rows(l.h);
@@ -919,17 +952,17 @@ static int layer_sweeps(mav_ctx* c, hipStream_t st, int k, int g, const float* r
         HIPCHK(hipStreamWaitEvent(c->pair_stream, c->pif_fork, 0));
         for (int s0 = 0; s0 < g; s0++) {
             const hipStream_t ss = (s0 & 1) ? c->pair_stream : st;
-            float *Min = w.Ma + (size_t)(s0 & 1) * 5 * n0, *Mout = w.Mb + (size_t)(s0 & 1) * 5 * n0;
+            float *Min = Ma + (size_t)(s0 & 1) * ms, *Mout = Mb + (size_t)(s0 & 1) * ms;
             const float *r0 = r0g + (size_t)s0 * rs, *r1 = r1g + (size_t)s0 * rs;
             float* fo = fdst + (size_t)s0 * fstride;
             const BandUpdate bu{flow_prev ? flow_prev + (size_t)s0 * fc_stride : nullptr, fc_stride, pw, ph, mul};
             if (p.J > 1) {
-                sweeps_band_major(c, ss, K_ITER, Min, Mout, r0, r1, rs, 1, l.w, l.h, T, p.J, fo, fstride, &bu, true);
+                sweeps_band_major(c, ss, kid, Min, Mout, ms, r0, r1, rs, 1, l.w, l.h, T, p.J, fo, fstride, &bu, true);
                 continue;
             }
             { ProfScope ps(c, K_UPDATE, ss);
-              launch_update_matrices(ss, r0, r1, rs, bu.flow_prev, fc_stride, pw, ph, mul, 1, l.w, l.h, Min, 5 * n0); }
-            sweeps_plain(c, ss, K_ITER, Min, Mout, r0, r1, rs, 1, l, fo, fstride, true);
+              launch_update_matrices(ss, r0, r1, rs, bu.flow_prev, fc_stride, pw, ph, mul, 1, l.w, l.h, Min, ms); }
+            sweeps_plain(c, ss, kid, Min, Mout, ms, r0, r1, rs, 1, l, fo, fstride, true);
         }
         prof_close_stream(c, c->pair_stream); prof_close_stream(c, st);
         HIPCHK(hipEventRecord(c->pif_join, c->pair_stream));
@@ -943,12 +976,12 @@ static int layer_sweeps(mav_ctx* c, hipStream_t st, int k, int g, const float* r
         for (int s0 = 0; s0 < g; s0 += p.half, idx++) {
             const int gs = g - s0 < p.half ? g - s0 : p.half;
             const hipStream_t ss = (idx & 1) ? c->pair_stream : st;
-            const size_t m_off = (size_t)(idx & 1) * p.half * 5 * n0;
+            const size_t m_off = (size_t)(idx & 1) * p.half * ms;
             const float *r0 = r0g + (size_t)s0 * rs, *r1 = r1g + (size_t)s0 * rs;
             { ProfScope ps(c, K_UPDATE, ss);
               launch_update_matrices(ss, r0, r1, rs, flow_prev ? flow_prev + (size_t)s0 * fc_stride : nullptr, fc_stride, pw, ph, mul, gs, l.w, l.h,
-                                     w.Ma + m_off, 5 * n0); }
-            sweeps_plain(c, ss, K_ITER_COARSE, w.Ma + m_off, w.Mb + m_off, r0, r1, rs, gs, l, fdst + (size_t)s0 * fstride, fstride, true);
+                                     Ma + m_off, ms); }
+            sweeps_plain(c, ss, K_ITER_COARSE, Ma + m_off, Mb + m_off, ms, r0, r1, rs, gs, l, fdst + (size_t)s0 * fstride, fstride, true);
         }
         prof_close_stream(c, c->pair_stream); prof_close_stream(c, st);
         HIPCHK(hipEventRecord(c->pif_join, c->pair_stream));
@@ -957,23 +990,23 @@ static int layer_sweeps(mav_ctx* c, hipStream_t st, int k, int g, const float* r
     }
     if (!p.m_per_sub) {
         ProfScope ps(c, K_UPDATE, st);
-        launch_update_matrices(st, r0g, r1g, rs, flow_prev, fc_stride, pw, ph, mul, g, l.w, l.h, w.Ma, 5 * n0);
+        launch_update_matrices(st, r0g, r1g, rs, flow_prev, fc_stride, pw, ph, mul, g, l.w, l.h, Ma, ms);
     }
     // Sub-groups are swept one after the other on one stream, so they all ping-pong M through the SAME two buffers (the first
     // sub-group's slots; option "share_m"): the M lines then stay hot in the Infinity Cache from pair to pair instead of leaving a
     // dead 83 MB copy behind per pair.  Measured at 1080p, 64 pairs: 27.6 / 28.0 ms shared vs 28.2 / 28.6 ms with per-slot buffers.
     for (int s0 = 0; s0 < g; s0 += p.sub) {
         const int gs = g - s0 < p.sub ? g - s0 : p.sub;
-        const size_t m_off = (p.m_per_sub && c->share_m) ? 0 : (size_t)s0 * 5 * n0;
+        const size_t m_off = (p.m_per_sub && c->share_m) ? 0 : (size_t)s0 * ms;
         const float *r0 = r0g + (size_t)s0 * rs, *r1 = r1g + (size_t)s0 * rs;
         if (p.m_per_sub) {
             ProfScope ps(c, K_UPDATE, st);
             launch_update_matrices(st, r0, r1, rs, flow_prev ? flow_prev + (size_t)s0 * fc_stride : nullptr, fc_stride, pw, ph, mul, gs, l.w,
-                                   l.h, w.Ma + m_off, 5 * n0);
+                                   l.h, Ma + m_off, ms);
         }
         float* fo = fdst + (size_t)s0 * fstride;
-        if (p.J > 1 && gs == 1) sweeps_band_major(c, st, K_ITER, w.Ma + m_off, w.Mb + m_off, r0, r1, rs, gs, l.w, l.h, T, p.J, fo, fstride);
-        else sweeps_plain(c, st, kid, w.Ma + m_off, w.Mb + m_off, r0, r1, rs, gs, l, fo, fstride);
+        if (p.J > 1 && gs == 1) sweeps_band_major(c, st, kid, Ma + m_off, Mb + m_off, ms, r0, r1, rs, gs, l.w, l.h, T, p.J, fo, fstride);
+        else sweeps_plain(c, st, kid, Ma + m_off, Mb + m_off, ms, r0, r1, rs, gs, l, fo, fstride);
     }
     return MAV_OK;
 }
@@ -1037,58 +1070,119 @@ static bool is_small_group(const mav_ctx* c, int g)
 // 1280x720 pair, profiles/r03/c2_side_stream.txt; all sweeps of a layer in one launch of resident workgroups that hand M' over through
 // flags -- a cross-CU hand-off costs what the kernel boundary costs: 0.419 vs 0.305 ms, profiles/r03/c2_resident_sweeps.txt.  For big
 // groups overlapping the finest layer's preparation with the coarse sweeps loses too: profiles/r02/ab_overlap_fine_prep_with_coarse_sweeps.log.)
-static int flow_group(mav_ctx* c, const uint8_t* prev, const uint8_t* next, int g, bool seq, float* flow_out)
+// The layer images of layers k_lo .. k_hi for F frames (the first `split` from run prev, the rest from run img2; img2 == nullptr: one
+// run) into regions Ik(k) with slot stride sk(k): every layer blur_multi_ok accepts through ONE launch, the others (long Gaussians)
+// through the two-pass kernels in chunks the H x w scratch holds; then ALL their expansions through one launch (per MAV_MAX_JOBS layers).
+template <typename IkFn, typename RkFn, typename SkFn>
+static void pyramid_multi(mav_ctx* c, hipStream_t st, const uint8_t* prev, const uint8_t* img2, int split, int F, int k_lo, int k_hi, IkFn Ik,
+                          RkFn Rk, SkFn sk)
+{
+    mav_ctx::WorkSet& w = c->ws;
+    const size_t n0 = c->n0;
+    BlurJobs bj{0, 0, {}};
+    PolyJobs pj{0, 0, {}};
+    auto flush_blur = [&]() { if (bj.n) { ProfScope ps(c, K_BLUR_RESIZE, st); launch_blur_multi(st, prev, img2, split, n0, F, c->W, c->H, bj); bj.n = 0; } };
+    auto flush_poly = [&]() { if (pj.n) { ProfScope ps(c, K_POLYEXP, st); launch_polyexp_multi(st, pj, F, c->pc); pj.n = 0; } };
+    for (int k = k_lo; k <= k_hi; k++) {
+        const Layer& l = c->layers[k];
+        if (blur_multi_ok(prev, img2, n0, c->W, c->H, l.w, l.h, blur_of(c, l), Ik(k), sk(k))) {
+            if (bj.n == MAV_MAX_JOBS) flush_blur();
+            BlurJob& J = bj.j[bj.n++];
+            J.out = Ik(k); J.out_stride = sk(k); J.bp = blur_of(c, l); J.w = l.w; J.h = l.h;
+        } else {
+            // a long Gaussian (or an unaligned finest layer): launches of its own.  The two-pass scratch holds (group + 1) H x W floats;
+            // a frame needs H x w of it
+            ProfScope ps(c, K_BLUR_RESIZE, st);
+            const size_t per = (size_t)c->H * l.w, cap_frames = (c->htmp_stride * (size_t)(c->group + 1)) / per;
+            const int chunk = (int)(cap_frames < (size_t)F ? cap_frames : (size_t)F);
+            for (int f0 = 0; f0 < F; f0 += chunk) {
+                const int n = F - f0 < chunk ? F - f0 : chunk;
+                const bool from2 = img2 && f0 >= split;
+                const uint8_t* a = from2 ? img2 + (size_t)(f0 - split) * n0 : prev + (size_t)f0 * n0;
+                launch_blur_resize(st, a, from2 ? nullptr : img2, from2 ? 0 : split - f0, n0, n, c->W, c->H, l.w, l.h, blur_of(c, l), w.Htmp, per,
+                                   Ik(k) + (size_t)f0 * sk(k), sk(k));
+            }
+        }
+        if (pj.n == MAV_MAX_JOBS) { flush_blur(); flush_poly(); }
+        PolyJob& P = pj.j[pj.n++];
+        P.I = Ik(k); P.R = Rk(k); P.I_stride = sk(k); P.R_stride = 5 * sk(k); P.w = l.w; P.h = l.h;
+    }
+    flush_blur();
+    flush_poly();
+}
+
+// DEEP LAYERS (kd .. top) of D pairs at once, on the compute stream; the flow of layer kd lands in deep.f[kd & 1], slot stride
+// 2 * c_stride[kd].  See mav_ctx::DeepSet.  Same tile functions on the same data as the per-group path: bit-identical flow.
+static int deep_layers(mav_ctx* c, const uint8_t* prev, const uint8_t* next, int D, bool seq)
+{
+    const hipStream_t st = c->stream;
+    const int L = (int)c->layers.size(), kd = c->kd;
+    const int F = seq ? D + 1 : 2 * D;
+    const uint8_t* img2 = seq ? nullptr : next;
+    const size_t base = c->c_off[kd];
+    auto Ik = [&](int k) { return c->deep.I + (size_t)F * (c->c_off[k] - base); };
+    auto Rk = [&](int k) { return c->deep.R + 5 * (size_t)F * (c->c_off[k] - base); };
+    auto sk = [&](int k) { return c->c_stride[k]; };
+    pyramid_multi(c, st, prev, img2, D, F, kd, L - 1, Ik, Rk, sk);
+    const float* flow_prev = nullptr;
+    int pw = 0, ph = 0;
+    size_t fp_stride = 0;
+    for (int k = L - 1; k >= kd; k--) {
+        const size_t rs = 5 * sk(k);
+        const float *r0 = Rk(k), *r1 = Rk(k) + (seq ? rs : rs * (size_t)D);
+        CHK(layer_sweeps(c, st, k, D, r0, r1, rs, flow_prev, fp_stride, pw, ph, c->deep.f[k & 1], 2 * sk(k), c->deep.Ma, c->deep.Mb, 5 * sk(k)));
+        flow_prev = c->deep.f[k & 1]; fp_stride = 2 * sk(k); pw = c->layers[k].w; ph = c->layers[k].h;
+    }
+    return MAV_OK;
+}
+
+// One group of g pairs: every coarse layer completely (top layer first: images, expansions, initial M, sweeps), then the finest layer.
+// deep_flow != nullptr: the layers from kd up have been computed already (deep_layers); the group starts at layer kd - 1 with
+// deep_flow (this group's first pair; slot stride deep_stride) as its coarser layer.
+// SMALL GROUPS (is_small_group: one 1080p pair, two 720p pairs ...; BASELINE config 2) are a chain of ~30 dependent launches that
+// each fill a fraction of the chip, ~4.5 us of boundary apiece.  For them the whole pyramid's layer images come from ONE launch and
+// all expansions from ONE launch (k_blur_multi / k_polyexp_multi: the workgroups of several layers in one grid, every layer into a
+// region of its own in Ic / Rc), instead of two launches per layer: the small layers ride along with the finest one.  Same tile
+// functions on the same data: bit-identical flow (tests/test_gpu_flow.py).
+// (Measured for such groups and not kept: the finest layer's images and expansions on a side stream underneath the coarse chain;
+// all sweeps of a layer in one launch of resident workgroups that hand M' over through flags -- HISTORY.md.)
+static int flow_group(mav_ctx* c, const uint8_t* prev, const uint8_t* next, int g, bool seq, float* flow_out, const float* deep_flow = nullptr,
+                      size_t deep_stride = 0)
 {
     mav_ctx::WorkSet& w = c->ws;
     const hipStream_t st = c->stream;
     const int L = (int)c->layers.size();
     const size_t n0 = c->n0, fc_stride = 2 * (c->n1 ? c->n1 : 1);
-    const float* flow_prev = nullptr;
-    int pw = 0, ph = 0;
-    if (is_small_group(c, g)) {
+    const float* flow_prev = deep_flow;
+    size_t fp_stride = deep_flow ? deep_stride : fc_stride;
+    const int k_top = deep_flow ? c->kd - 1 : L - 1;
+    int pw = deep_flow ? c->layers[c->kd].w : 0, ph = deep_flow ? c->layers[c->kd].h : 0;
+    if (!deep_flow && is_small_group(c, g)) {
         const int F = seq ? g + 1 : 2 * g;                                // frames: one run of g + 1, or the prev run and the next run
         const uint8_t* img2 = seq ? nullptr : next;
         auto Ik = [&](int k) { return k ? w.Ic + (size_t)F * c->c_off[k] : w.I; };
         auto Rk = [&](int k) { return k ? w.Rc + 5 * (size_t)F * c->c_off[k] : w.R; };
         auto sk = [&](int k) { return k ? c->c_stride[k] : n0; };
-        BlurJobs bj{0, 0, {}};
-        PolyJobs pj{0, 0, {}};
-        for (int k = 0; k < L; k++) {
-            const Layer& l = c->layers[k];
-            if (blur_multi_ok(prev, img2, n0, c->W, c->H, l.w, l.h, blur_of(c, l), Ik(k), sk(k))) {
-                BlurJob& J = bj.j[bj.n++];
-                J.out = Ik(k); J.out_stride = sk(k); J.bp = blur_of(c, l); J.w = l.w; J.h = l.h;
-            } else {                                                      // a long Gaussian (or an unaligned finest layer): launches of its own;
-                ProfScope ps(c, K_BLUR_RESIZE, st);                       // the two-pass scratch holds g + 1 frames
-                if (F <= g + 1)
-                    launch_blur_resize(st, prev, img2, g, n0, F, c->W, c->H, l.w, l.h, blur_of(c, l), w.Htmp, c->htmp_stride, Ik(k), sk(k));
-                else {
-                    launch_blur_resize(st, prev, nullptr, 0, n0, g, c->W, c->H, l.w, l.h, blur_of(c, l), w.Htmp, c->htmp_stride, Ik(k), sk(k));
-                    launch_blur_resize(st, next, nullptr, 0, n0, g, c->W, c->H, l.w, l.h, blur_of(c, l), w.Htmp, c->htmp_stride,
-                                       Ik(k) + (size_t)g * sk(k), sk(k));
-                }
-            }
-            PolyJob& P = pj.j[pj.n++];
-            P.I = Ik(k); P.R = Rk(k); P.I_stride = sk(k); P.R_stride = 5 * sk(k); P.w = l.w; P.h = l.h;
-        }
-        if (bj.n) { ProfScope ps(c, K_BLUR_RESIZE, st); launch_blur_multi(st, prev, img2, g, n0, F, c->W, c->H, bj); }
-        { ProfScope ps(c, K_POLYEXP, st); launch_polyexp_multi(st, pj, F, c->pc); }
+        pyramid_multi(c, st, prev, img2, g, F, 0, L - 1, Ik, Rk, sk);
         for (int k = L - 1; k >= 0; k--) {
             const size_t rs = 5 * sk(k);
             const float *r0 = Rk(k), *r1 = Rk(k) + (seq ? rs : rs * (size_t)g);
-            CHK(layer_sweeps(c, st, k, g, r0, r1, rs, flow_prev, fc_stride, pw, ph, k ? w.fc[k & 1] : flow_out, k ? fc_stride : 2 * n0));
+            CHK(layer_sweeps(c, st, k, g, r0, r1, rs, flow_prev, fc_stride, pw, ph, k ? w.fc[k & 1] : flow_out, k ? fc_stride : 2 * n0, w.Ma, w.Mb, 5 * n0));
             flow_prev = w.fc[k & 1]; pw = c->layers[k].w; ph = c->layers[k].h;
         }
         return MAV_OK;
     }
     const float *r0 = nullptr, *r1 = nullptr;
-    for (int k = L - 1; k >= 0; k--) {
+    for (int k = k_top; k >= 0; k--) {
         layer_expansions(c, st, k, prev, next, g, seq, w.I, w.R, &r0, &r1);
-        CHK(layer_sweeps(c, st, k, g, r0, r1, 5 * n0, flow_prev, fc_stride, pw, ph, k ? w.fc[k & 1] : flow_out, k ? fc_stride : 2 * n0));
-        flow_prev = w.fc[k & 1]; pw = c->layers[k].w; ph = c->layers[k].h;
+        CHK(layer_sweeps(c, st, k, g, r0, r1, 5 * n0, flow_prev, fp_stride, pw, ph, k ? w.fc[k & 1] : flow_out, k ? fc_stride : 2 * n0, w.Ma, w.Mb, 5 * n0));
+        flow_prev = w.fc[k & 1]; fp_stride = fc_stride; pw = c->layers[k].w; ph = c->layers[k].h;
     }
     return MAV_OK;
 }
+
+// does a call of `batch` pairs run its deep layers once for the whole call (deep_layers) instead of once per group?
+static bool use_deep_batch(const mav_ctx* c, int batch) { return c->deep_batch && c->kd > 0 && batch > c->group; }
 
 extern "C" int mav_farneback_dev(mav_ctx* c, const uint8_t* prev, const uint8_t* next, int batch, float* flow)
 {
@@ -1101,10 +1195,18 @@ extern "C" int mav_farneback_dev(mav_ctx* c, const uint8_t* prev, const uint8_t*
     // every inner frame in two pairs.  Each group then blurs and expands its g + 1 frames once instead of 2 g (same arithmetic per
     // frame: the flow is bit-identical to the two-batch form; tests/test_gpu_flow.py).  Option "share_frames" = 0 switches it off.
     const bool seq = c->share_frames && next == prev + c->n0;
-    for (int g0 = 0; g0 < batch; g0 += c->group) {
-        const int g = batch - g0 < c->group ? batch - g0 : c->group;
-        CHK(flow_group(c, prev + (size_t)g0 * c->n0, next + (size_t)g0 * c->n0, g, seq, flow + (size_t)g0 * 2 * c->n0));
-        CHK(check_launch("farneback kernels"));
+    const bool deep = use_deep_batch(c, batch);
+    const int chunk = deep ? c->deep_cap : batch;
+    for (int d0 = 0; d0 < batch; d0 += chunk) {
+        const int D = batch - d0 < chunk ? batch - d0 : chunk;
+        const size_t dstride = deep ? 2 * c->c_stride[c->kd] : 0;
+        if (deep) CHK(deep_layers(c, prev + (size_t)d0 * c->n0, next + (size_t)d0 * c->n0, D, seq));
+        for (int g0 = d0; g0 < d0 + D; g0 += c->group) {
+            const int g = d0 + D - g0 < c->group ? d0 + D - g0 : c->group;
+            CHK(flow_group(c, prev + (size_t)g0 * c->n0, next + (size_t)g0 * c->n0, g, seq, flow + (size_t)g0 * 2 * c->n0,
+                           deep ? c->deep.f[c->kd & 1] + (size_t)(g0 - d0) * dstride : nullptr, dstride));
+            CHK(check_launch("farneback kernels"));
+        }
     }
     c->last_flow = flow;
     return MAV_OK;
@@ -1126,12 +1228,15 @@ extern "C" int mav_schedule_info(mav_ctx* c, int batch, char* buf, size_t cap)
         o += t;
     }
     const int g = batch < c->group ? batch : c->group;
-    snprintf(t, sizeof(t), "\"pairs_per_group\": %d, \"pyramid_in_two_launches\": %s, \"layers\": [", g, is_small_group(c, g) ? "true" : "false");
+    const bool deep = use_deep_batch(c, batch);
+    const int D = deep ? (batch < c->deep_cap ? batch : c->deep_cap) : 0;
+    snprintf(t, sizeof(t), "\"pairs_per_group\": %d, \"pyramid_in_two_launches\": %s, \"deep_layers_from\": %d, \"deep_pairs\": %d, \"layers\": [", g,
+             (!deep && is_small_group(c, g)) ? "true" : "false", deep ? c->kd : 0, D);
     o += t;
     static const char* const mode_names[] = {"one stream", "two pairs in flight, band-major", "two sub-groups in flight"};
     for (int k = 0; k < (int)c->layers.size(); k++) {
         const Layer& l = c->layers[k];
-        const SweepPlan p = plan_sweeps(c, k, g, l.w % 4 == 0 && c->fb.winsize / 2 == 6);
+        const SweepPlan p = plan_sweeps(c, k, (deep && k >= c->kd) ? D : g, l.w % 4 == 0 && c->fb.winsize / 2 == 6);
         snprintf(t, sizeof(t), "%s{\"layer\": %d, \"w\": %d, \"h\": %d, \"blur\": \"%s\", \"sweeps\": \"%s\", \"pairs_per_launch\": %d, \"bands\": %d}",
                  k ? ", " : "", k, l.w, l.h,
                  (l.w == c->W && l.h == c->H) ? "3x3" : (blur_resize_is_fused(c->W, c->H, l.w, l.h, l.ksize) ? "fused" : "two-pass"),

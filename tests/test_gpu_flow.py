@@ -353,7 +353,8 @@ def test_options_are_reported_and_validated(mav):
         assert info["layers"][0]["sweeps"].startswith("two pairs in flight") and info["layers"][0]["bands"] == 2
         assert info["layers"][1]["blur"] == "fused" and info["layers"][1]["pairs_per_launch"] == 4
         for name, v in (("band_mb", 40), ("coarse_half", 3), ("strip", 20), ("phi_yloop", 4), ("phi_screen", 0), ("share_m", 0),
-                        ("coarse_cache_mb", 100), ("bands", 3), ("group_fine", 2), ("small_batch", 0), ("sweep_write_through", 1)):
+                        ("coarse_cache_mb", 100), ("bands", 3), ("group_fine", 2), ("small_batch", 0), ("sweep_write_through", 1),
+                        ("deep_batch", 0), ("coarse_bands", 0)):
             c.set_option(name, v)
             assert c.get_option(name) == v
             assert c.schedule_info(64)[name] == v
@@ -451,3 +452,53 @@ def test_two_pairs_in_flight_give_the_same_flow(mav, size, batch, group):
         busy = c.profile_busy("blur_iter")
         c.profile_enable(False)
         assert 0 < busy <= prof["blur_iter"][0] * 1.0001
+
+
+@pytest.mark.parametrize("size,levels,batch,group,band_mb", [((1920, 1080), 3, 5, 2, 8), ((1000, 562), 4, 7, 3, 8), ((640, 480), 2, 6, 2, 8),
+                                                             ((3840, 2160), 5, 3, 2, 86)])
+def test_deep_layers_once_per_call_and_banded_coarse_layers_are_bit_identical(mav, size, levels, batch, group, band_mb):
+    """Round 4's two schedule changes for many-layer pyramids (BASELINE config 5: 3840x2160, five layers).
+    "deep_batch": the layers at the top of the pyramid (each at most 1/32 of the frame) run ONCE for all pairs of a call -- their images
+    from one launch, their expansions from one launch, their sweeps over all pairs -- and the groups start below them.
+    "coarse_bands": a coarse layer whose per-pair working set exceeds a band is swept like the finest layer (pairs alternating between
+    the two streams, band-major, initial M band by band).  Same tile functions on the same data: the flow must equal the per-group,
+    one-stream schedule bit for bit -- ragged last group, a frame sequence, one pair, call after call -- and the chain after it too."""
+    from mavflow import _lib
+    W, H = size
+    prev, nxt = synth.make_batch(W, H, batch, distinct=min(batch, 3))
+    smp = np.stack([synth.foe_samples(W, H, b) for b in range(batch)])
+    with _lib.Context(W, H, batch, _lib.fb_defaults(levels=levels)) as c:
+        c.set_option("group", group)
+        c.set_option("band_mb", band_mb)
+        for name in ("deep_batch", "coarse_bands"):
+            c.set_option(name, 0)
+        c.set_option("pairs_in_flight", 1)
+        info = c.schedule_info(batch)
+        assert info["deep_layers_from"] == 0 and all(l["sweeps"] == "one stream" for l in info["layers"])
+        ref = c.farneback(prev, nxt)
+        chain = c.process_batch(prev, nxt, smp)
+        seq = synth.make_sequence(W, H, batch + 1)
+        seq_ref = c.farneback_sequence(seq)
+        c.set_option("pairs_in_flight", 2)
+        for deep, cb in ((1, 0), (0, 1), (1, 1)):
+            c.set_option("deep_batch", deep)
+            c.set_option("coarse_bands", cb)
+            info = c.schedule_info(batch)
+            n_layers = len(info["layers"])
+            if deep and n_layers > 2:
+                assert info["deep_layers_from"] >= 2 and info["deep_pairs"] == batch
+            w1, h1 = info["layers"][1]["w"], info["layers"][1]["h"]
+            big = w1 % 4 == 0 and w1 * h1 * 80 > (band_mb << 20) and ((h1 + 15) // 16) // 12 >= 2
+            assert big == (size in ((1920, 1080), (3840, 2160)))
+            if cb and big:
+                assert info["layers"][1]["sweeps"].startswith("two pairs in flight") and info["layers"][1]["bands"] >= 2, info["layers"][1]
+            for rep in range(2):
+                out = c.farneback(prev, nxt)
+                assert np.array_equal(out, ref), (deep, cb, rep, int((out != ref).sum()))
+            assert np.array_equal(c.farneback_sequence(seq), seq_ref), (deep, cb)
+            assert np.array_equal(c.farneback(prev[:1], nxt[:1]), ref[:1])
+            assert np.array_equal(c.farneback(prev[:group + 1], nxt[:group + 1]), ref[:group + 1])
+        two = c.process_batch(prev, nxt, smp)
+        for key in ("flow", "mask_fixed", "mask_dyn"):
+            assert np.array_equal(two[key], chain[key]), key
+        assert two["results"].tobytes() == chain["results"].tobytes()
