@@ -98,8 +98,8 @@ int mav_device_count(void);       /* <= 0 when no GPU is visible */
  *   "deep_batch"       default 1: when a call has more than one group, the layers at the top of the pyramid that are each at most 1/32
  *                      of the frame (layers 2 - 4 of the 3840x2160 / 5-layer preset: latency-bound chains of tiny launches) run ONCE for
  *                      up to 64 pairs of the call before the groups start, instead of once per group
- *   "coarse_bands"     default 1: a coarse layer whose per-pair working set exceeds "band_mb" (layer 1 of the 4K preset, 106 MB) is swept
- *                      like the finest layer: pairs alternating between the two streams, band by band
+ *   "coarse_bands"     default 0: 1 = a coarse layer whose per-pair working set exceeds "band_mb" (layer 1 of the 4K preset, 106 MB) is
+ *                      swept like the finest layer, pairs alternating between the two streams band by band (measured slower: off)
  *   "sweep_write_through"  -1 (default): the sweeps' M' stores are write-through (sc1) in the two-stream schedules, plain otherwise;
  *                      0 / 1: never / always
  *   "strip"            width in tiles of the column strips of the XCD-aware tile order (0 = automatic)

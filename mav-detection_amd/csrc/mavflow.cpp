@@ -230,9 +230,6 @@ struct mav_ctx {
     bool group_fine_set = false;     // "group_fine" given explicitly
     hipStream_t pair_stream = nullptr;
     hipEvent_t pif_fork = nullptr, pif_join = nullptr;
-    hipStream_t deep_stream = nullptr;        // the deep layers' chain runs here, underneath the first group's layer images / expansions (option "deep_overlap")
-    hipEvent_t deep_fork = nullptr, deep_join = nullptr;
-    bool deep_overlap = true;
     bool share_frames = true;        // option "share_frames": expand a frame once when next == prev + one frame (a frame sequence)
     int coarse_cache_mb = 220;       // coarse layers: pairs per launch capped so that the sweeps' working set stays below this (0 = no cap)
     // tuning options that used to be environment variables (mav_set_option / mav_get_option; all reported by mav_schedule_info)
@@ -384,7 +381,7 @@ static int ensure_workspace(mav_ctx* c)
 
 static int sync_all_streams(mav_ctx* c)
 {
-    for (hipStream_t st : {c->stream, c->pair_stream, c->deep_stream})
+    for (hipStream_t st : {c->stream, c->pair_stream})
         if (st) HIPCHK(hipStreamSynchronize(st));
     return MAV_OK;
 }
@@ -406,8 +403,8 @@ extern "C" int mav_destroy(mav_ctx* c)
     for (auto& blk : c->scratch) if (blk.p) hipFree(blk.p);
     for (auto& r : c->prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     if (c->prof_base) hipEventDestroy(c->prof_base);
-    for (hipEvent_t e : {c->t0, c->t1, c->copy_done, c->compute_mark, c->pif_fork, c->pif_join, c->deep_fork, c->deep_join}) if (e) hipEventDestroy(e);
-    for (hipStream_t st : {c->deep_stream, c->pair_stream, c->copy_stream, c->stream}) if (st) hipStreamDestroy(st);
+    for (hipEvent_t e : {c->t0, c->t1, c->copy_done, c->compute_mark, c->pif_fork, c->pif_join}) if (e) hipEventDestroy(e);
+    for (hipStream_t st : {c->pair_stream, c->copy_stream, c->stream}) if (st) hipStreamDestroy(st);
     delete c;
     return MAV_OK;
 }
@@ -444,8 +441,8 @@ extern "C" int mav_create(mav_ctx** out, int device, int W, int H, int max_batch
     c->device = device; c->W = W; c->H = H; c->max_batch = max_batch; c->fb = fb;
     auto bail = [&](int code) { mav_destroy(c); return code; };
 #define HIPB(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fail(e_ == hipErrorOutOfMemory ? MAV_ERR_OOM : MAV_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); return bail(e_ == hipErrorOutOfMemory ? MAV_ERR_OOM : MAV_ERR_HIP); } } while (0)
-    for (hipStream_t* st : {&c->stream, &c->copy_stream, &c->pair_stream, &c->deep_stream}) HIPB(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
-    for (hipEvent_t* e : {&c->copy_done, &c->compute_mark, &c->pif_fork, &c->pif_join, &c->deep_fork, &c->deep_join})
+    for (hipStream_t* st : {&c->stream, &c->copy_stream, &c->pair_stream}) HIPB(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+    for (hipEvent_t* e : {&c->copy_done, &c->compute_mark, &c->pif_fork, &c->pif_join})
         HIPB(hipEventCreateWithFlags(e, hipEventDisableTiming));
     HIPB(hipEventCreate(&c->t0));
     HIPB(hipEventCreate(&c->t1));
@@ -525,7 +522,7 @@ static const OptionDesc kOptions[] = {
     {"group", 1, 1 << 20}, {"group_fine", 0, 1 << 20}, {"bands", 0, 8}, {"pairs_in_flight", 1, 2}, {"band_mb", 8, 1 << 20},
     {"coarse_cache_mb", 0, 1 << 20}, {"coarse_half", 0, 1 << 20}, {"share_m", 0, 1}, {"share_frames", 0, 1}, {"strip", 0, 1 << 20},
     {"phi_screen", 0, 1}, {"phi_yloop", 0, 1 << 20}, {"small_batch", 0, 1}, {"sweep_write_through", -1, 1}, {"deep_batch", 0, 1},
-    {"coarse_bands", 0, 1}, {"deep_overlap", 0, 1},
+    {"coarse_bands", 0, 1},
 };
 static long* option_slot(mav_ctx* c, const char* name, long* tmp)
 {
@@ -535,7 +532,6 @@ static long* option_slot(mav_ctx* c, const char* name, long* tmp)
         {"band_mb", c->pif_band_mb}, {"coarse_cache_mb", c->coarse_cache_mb}, {"coarse_half", c->coarse_half}, {"share_m", c->share_m},
         {"share_frames", c->share_frames}, {"strip", c->strip}, {"phi_screen", c->phi_screen}, {"phi_yloop", c->phi_yloop},
         {"small_batch", c->small_batch}, {"sweep_write_through", c->sweep_wt}, {"deep_batch", c->deep_batch}, {"coarse_bands", c->coarse_bands},
-        {"deep_overlap", c->deep_overlap},
     };
     for (auto& e : cur) if (!strcmp(e.n, name)) { *tmp = e.v; return tmp; }
     return nullptr;
@@ -582,7 +578,6 @@ extern "C" int mav_set_option(mav_ctx* c, const char* name, long value)
     else if (!strcmp(name, "sweep_write_through")) c->sweep_wt = v;
     else if (!strcmp(name, "deep_batch")) c->deep_batch = v != 0;
     else if (!strcmp(name, "coarse_bands")) c->coarse_bands = v != 0;
-    else if (!strcmp(name, "deep_overlap")) c->deep_overlap = v != 0;
     return MAV_OK;
 }
 
@@ -1152,7 +1147,7 @@ static int deep_layers(mav_ctx* c, hipStream_t st, const uint8_t* prev, const ui
 // (Measured for such groups and not kept: the finest layer's images and expansions on a side stream underneath the coarse chain;
 // all sweeps of a layer in one launch of resident workgroups that hand M' over through flags -- HISTORY.md.)
 static int flow_group(mav_ctx* c, const uint8_t* prev, const uint8_t* next, int g, bool seq, float* flow_out, const float* deep_flow = nullptr,
-                      size_t deep_stride = 0, hipEvent_t deep_ready = nullptr /* the top layer's sweeps wait for it (deep chain on its own stream) */)
+                      size_t deep_stride = 0)
 {
     mav_ctx::WorkSet& w = c->ws;
     const hipStream_t st = c->stream;
@@ -1180,7 +1175,6 @@ static int flow_group(mav_ctx* c, const uint8_t* prev, const uint8_t* next, int 
     const float *r0 = nullptr, *r1 = nullptr;
     for (int k = k_top; k >= 0; k--) {
         layer_expansions(c, st, k, prev, next, g, seq, w.I, w.R, &r0, &r1);
-        if (k == k_top && deep_ready) { prof_close_stream(c, st); HIPCHK(hipStreamWaitEvent(st, deep_ready, 0)); }
         CHK(layer_sweeps(c, st, k, g, r0, r1, 5 * n0, flow_prev, fp_stride, pw, ph, k ? w.fc[k & 1] : flow_out, k ? fc_stride : 2 * n0, w.Ma, w.Mb, 5 * n0));
         flow_prev = w.fc[k & 1]; fp_stride = fc_stride; pw = c->layers[k].w; ph = c->layers[k].h;
     }
@@ -1206,27 +1200,13 @@ extern "C" int mav_farneback_dev(mav_ctx* c, const uint8_t* prev, const uint8_t*
     for (int d0 = 0; d0 < batch; d0 += chunk) {
         const int D = batch - d0 < chunk ? batch - d0 : chunk;
         const size_t dstride = deep ? 2 * c->c_stride[c->kd] : 0;
-        // The deep chain is a run of tiny latency-bound launches: it goes to a stream of its own (pair_stream beside it for its two
-        // sub-groups in flight) and the first group's top-layer images / expansions -- HBM streaming work that depends on nothing but
-        // the frames -- run on the compute stream meanwhile; that group's first sweeps wait for the deep flow (option "deep_overlap").
-        hipEvent_t ready = nullptr;
-        // (the only buffer the two sides could share is the two-pass blur's scratch: no overlap when layer kd - 1 needs it too)
-        const Layer& lt = c->layers[deep ? c->kd - 1 : 0];
-        const bool overlap = deep && c->deep_overlap &&
-                             !blur_resize_needs_tmp(prev, seq ? nullptr : next, c->n0, c->W, c->H, lt.w, lt.h, blur_of(c, lt), c->ws.I, c->n0);
-        if (overlap) {
-            prof_close_stream(c, c->stream);
-            HIPCHK(hipEventRecord(c->deep_fork, c->stream));
-            HIPCHK(hipStreamWaitEvent(c->deep_stream, c->deep_fork, 0));
-            CHK(deep_layers(c, c->deep_stream, prev + (size_t)d0 * c->n0, next + (size_t)d0 * c->n0, D, seq));
-            prof_close_stream(c, c->deep_stream);
-            HIPCHK(hipEventRecord(c->deep_join, c->deep_stream));
-            ready = c->deep_join;
-        } else if (deep) CHK(deep_layers(c, c->stream, prev + (size_t)d0 * c->n0, next + (size_t)d0 * c->n0, D, seq));
+        // (Measured and not kept: the deep chain on a stream of its own underneath the first group's top-layer images / expansions --
+        // 592 vs 597 pairs/s at 3840x2160 / 5 layers / 16 pairs: the fork / join events cost more than the overlap hides.)
+        if (deep) CHK(deep_layers(c, c->stream, prev + (size_t)d0 * c->n0, next + (size_t)d0 * c->n0, D, seq));
         for (int g0 = d0; g0 < d0 + D; g0 += c->group) {
             const int g = d0 + D - g0 < c->group ? d0 + D - g0 : c->group;
             CHK(flow_group(c, prev + (size_t)g0 * c->n0, next + (size_t)g0 * c->n0, g, seq, flow + (size_t)g0 * 2 * c->n0,
-                           deep ? c->deep.f[c->kd & 1] + (size_t)(g0 - d0) * dstride : nullptr, dstride, g0 == d0 ? ready : nullptr));
+                           deep ? c->deep.f[c->kd & 1] + (size_t)(g0 - d0) * dstride : nullptr, dstride));
             CHK(check_launch("farneback kernels"));
         }
     }

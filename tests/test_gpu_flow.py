@@ -354,7 +354,7 @@ def test_options_are_reported_and_validated(mav):
         assert info["layers"][1]["blur"] == "fused" and info["layers"][1]["pairs_per_launch"] == 4
         for name, v in (("band_mb", 40), ("coarse_half", 3), ("strip", 20), ("phi_yloop", 4), ("phi_screen", 0), ("share_m", 0),
                         ("coarse_cache_mb", 100), ("bands", 3), ("group_fine", 2), ("small_batch", 0), ("sweep_write_through", 1),
-                        ("deep_batch", 0), ("coarse_bands", 1), ("deep_overlap", 0)):
+                        ("deep_batch", 0), ("coarse_bands", 1)):
             c.set_option(name, v)
             assert c.get_option(name) == v
             assert c.schedule_info(64)[name] == v
@@ -480,10 +480,9 @@ def test_deep_layers_once_per_call_and_banded_coarse_layers_are_bit_identical(ma
         seq = synth.make_sequence(W, H, batch + 1)
         seq_ref = c.farneback_sequence(seq)
         c.set_option("pairs_in_flight", 2)
-        for deep, cb, ov in ((1, 0, 0), (0, 1, 1), (1, 1, 1), (1, 0, 1)):
+        for deep, cb in ((1, 0), (0, 1), (1, 1)):
             c.set_option("deep_batch", deep)
             c.set_option("coarse_bands", cb)
-            c.set_option("deep_overlap", ov)                # the deep chain on a stream of its own underneath the first group's preparation
             info = c.schedule_info(batch)
             n_layers = len(info["layers"])
             if deep and n_layers > 2:
@@ -495,7 +494,7 @@ def test_deep_layers_once_per_call_and_banded_coarse_layers_are_bit_identical(ma
                 assert info["layers"][1]["sweeps"].startswith("two pairs in flight") and info["layers"][1]["bands"] >= 2, info["layers"][1]
             for rep in range(2):
                 out = c.farneback(prev, nxt)
-                assert np.array_equal(out, ref), (deep, cb, ov, rep, int((out != ref).sum()))
+                assert np.array_equal(out, ref), (deep, cb, rep, int((out != ref).sum()))
             assert np.array_equal(c.farneback_sequence(seq), seq_ref), (deep, cb)
             assert np.array_equal(c.farneback(prev[:1], nxt[:1]), ref[:1])
             assert np.array_equal(c.farneback(prev[:group + 1], nxt[:group + 1]), ref[:group + 1])
