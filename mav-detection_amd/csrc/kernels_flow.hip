@@ -489,16 +489,139 @@ static __device__ __forceinline__ void blur_fused_tile(const uint8_t* __restrict
         if (dx < w) out[(size_t)dy * w + dx] = v;
     }
 }
+
+// The fused tile again, for the cases that carry the load (ksize 5 and 13 -- layer 1 of the reference's preset, layers 1 - 2 of the
+// 4K / 5-layer one; dword-addressable frames; coordinate tables present): same H-pass / V-pass functions on the same values as
+// blur_fused_tile, hence the same bits, with the bookkeeping around them cut down -- round 3's form issued ~1000 VALU + ~520 SALU
+// instructions per wave for ~190 filter FMAs per thread:
+//   * the resize coordinates come from the layer's tables (bp.xs / xf / ys / yf) instead of double-precision arithmetic per thread;
+//   * KS is a template argument of the WHOLE tile (no run-time dispatch inside the loops; the V pass unrolls for 13 taps too);
+//   * staging: a wave owns rows wv, wv + 4, ...; row addresses are wave-uniform (scalar), a lane adds its word offset; six rows'
+//     loads in flight; every staged row lies inside the image (ylo + row <= yhi <= H - 1), so no clamping;
+//   * the H pass does not clamp its row index: rows past n_rows (at most 3, LDS the launch allocates) are computed and not stored;
+//   * interior tiles (every row's taps inside the image) take a V pass without the reflect-101 tests.
+template <int KS>
+static __device__ __forceinline__ float blur_v1_interior(const float* __restrict__ col, int s0, float f, const BlurParams& bp)
+{
+    constexpr int r = KS >> 1;
+    float px[KS + 1];
+#pragma unroll
+    for (int t = 0; t <= KS; t++) px[t] = col[(s0 - r + t) * 64];
+    float b0 = 0.f, b1 = 0.f;
+#pragma unroll
+    for (int t = 0; t < KS; t++) { const float g = bp.g[t]; b0 = fmaf(g, px[t], b0); b1 = fmaf(g, px[t + 1], b1); }
+    return fmaf(b1, f, b0 * (1.f - f));
+}
+template <int KS>
+static __device__ __forceinline__ void blur_fused_tile_fast(const uint8_t* __restrict__ base, float* __restrict__ out, int W, int H, int w, int h,
+                                                            const BlurParams& bp, int rows_cap, int pitch_w, int tile_x, int tile_y,
+                                                            float* __restrict__ hrows)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int r = KS >> 1;
+    const int dx = tile_x * 64 + lane, dxc = min(dx, w - 1);
+    const int dy0 = tile_y * FB_TH, dy1 = min(dy0 + FB_TH, h) - 1;
+    const int dyc = min(dy0 + (lane & (FB_TH - 1)), h - 1);
+    const int s0 = bp.xs[dxc];
+    const float f = bp.xf[dxc];
+    const int row_s = bp.ys[dyc];                                           // lane L < 16: source row / weight of destination row dy0 + L
+    const float row_f = bp.yf[dyc];
+    int xb, words;
+    tile_columns(s0, bp, &xb, &words);
+    words = min(words, pitch_w);
+    const int off = s0 - r - xb;
+    uint32_t* sw = (uint32_t*)(hrows + rows_cap * 64);
+    const int sa = __builtin_amdgcn_readlane(row_s, 0), sb = __builtin_amdgcn_readlane(row_s, FB_TH - 1);
+    const int ylo = max(sa - r, 0), yhi = min(sb + 1 + r, H - 1);
+    const int n_rows = min(yhi - ylo + 1, rows_cap);
+    // ---- stage the u8 source rows [ylo, ylo + n_rows), byte columns [xb, xb + 4 words)
+    {
+        const int wlo = xb < 0 ? (-xb) >> 2 : 0, whi = min(words, (W - xb) >> 2);
+        const int nw = whi - wlo;                                            // dwords of a row that lie inside the image
+        const uint8_t* g0 = base + (size_t)ylo * W + (xb + 4 * wlo);         // wave-uniform
+        uint32_t* s00 = sw + wlo;
+        for (int c0 = 0; c0 < nw; c0 += 64) {
+            const int wd = c0 + lane;
+            const bool ok = wd < nw;
+            const unsigned lo = 4u * (unsigned)(ok ? wd : 0);
+            for (int row0 = wv; row0 < n_rows; row0 += 24) {
+                uint32_t v[6];
+#pragma unroll
+                for (int u = 0; u < 6; u++) {
+                    const int row = min(row0 + 4 * u, n_rows - 1);           // (wave-uniform)
+                    v[u] = *(const uint32_t*)(g0 + ((unsigned)(row * W) + lo));
+                }
+#pragma unroll
+                for (int u = 0; u < 6; u++) {
+                    const int row = row0 + 4 * u;
+                    if (ok && row < n_rows) s00[row * pitch_w + wd] = v[u];
+                }
+            }
+        }
+        const int n_left = 4 * wlo, n_out = n_left + 4 * max(words - whi, 0);
+        if (n_out > 0) {                                                     // the few columns outside the image, reflected, byte by byte
+            uint8_t* sb8 = (uint8_t*)sw;
+            for (int row = wv; row < n_rows; row += 4) {
+                const uint8_t* p = base + (size_t)(ylo + row) * W;
+                for (int j = lane; j < n_out; j += 64) {
+                    const int col = j < n_left ? j : 4 * whi + (j - n_left);
+                    sb8[row * pitch_w * 4 + col] = p[reflect101d(xb + col, W)];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- horizontal pass: staged bytes -> hrows (n_rows x 64 f32)
+    for (int i = wv * 4; i < n_rows; i += 16) {
+        float o[4];
+        const uint32_t* rw = sw + i * pitch_w;
+        blur_h4_stream_t<KS>([&](int k, int wi) { return rw[k * pitch_w + wi]; }, off, f, bp, o);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (i + k < n_rows) hrows[(i + k) * 64 + lane] = o[k];
+    }
+    __syncthreads();
+    // ---- vertical pass
+    const float* col = hrows + lane - ylo * 64;
+    const bool interior = sa - r >= 0 && sb + 1 + r < H;                    // wave-uniform: no row of the tile touches the border
+#pragma unroll
+    for (int j = 0; j < FB_TH / 4; j++) {
+        const int dy = dy0 + j * 4 + wv;                                     // wave-uniform
+        if (dy > dy1) break;
+        const int t0 = __builtin_amdgcn_readlane(row_s, j * 4 + wv);
+        const float tf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(row_f), j * 4 + wv));
+        const float v = interior ? blur_v1_interior<KS>(col, t0, tf, bp) : blur_v1([&](int y) { return col[y * 64]; }, H, t0, tf, bp);
+        if (dx < w) out[(size_t)dy * w + dx] = v;
+    }
+}
+// does a fused layer take the fast tile?  (dword-addressable frames, staged form, tables, ksize 5 or 13)
+static __host__ __device__ __forceinline__ bool fused_fast_ok(const BlurParams& bp, int pitch_w, int dword_ok)
+{
+    return dword_ok && pitch_w > 0 && bp.xs != nullptr && (bp.ksize == 5 || bp.ksize == 13);
+}
+static __device__ __forceinline__ void blur_fused_any(const uint8_t* __restrict__ base, float* __restrict__ out, int W, int H, int w, int h,
+                                                      const BlurParams& bp, int rows_cap, int pitch_w, int dword_ok, int tile_x, int tile_y,
+                                                      float* __restrict__ hrows)
+{
+    if (fused_fast_ok(bp, pitch_w, dword_ok)) {
+        if (bp.ksize == 5) blur_fused_tile_fast<5>(base, out, W, H, w, h, bp, rows_cap, pitch_w, tile_x, tile_y, hrows);
+        else blur_fused_tile_fast<13>(base, out, W, H, w, h, bp, rows_cap, pitch_w, tile_x, tile_y, hrows);
+    } else
+        blur_fused_tile(base, out, W, H, w, h, bp, rows_cap, pitch_w, dword_ok, tile_x, tile_y, hrows);
+}
 __global__ __launch_bounds__(256) void k_blur_resize_fused(const uint8_t* __restrict__ img, const uint8_t* __restrict__ img2, int split,
                                                            size_t img_stride, int W, int H, int w, int h, BlurParams bp,
                                                            float* __restrict__ out, size_t out_stride, int rows_cap, int pitch_w, int dword_ok)
 {
-    extern __shared__ __attribute__((aligned(16))) float hrows[];       // [rows_cap][64] f32, then [rows_cap][pitch_w] dwords of u8
-    blur_fused_tile(image_of(img, img2, split, img_stride, blockIdx.z), out + (size_t)blockIdx.z * out_stride, W, H, w, h, bp, rows_cap, pitch_w,
-                    dword_ok, blockIdx.x, blockIdx.y, hrows);
+    extern __shared__ __attribute__((aligned(16))) float hrows[];       // [rows_cap][64] f32, then [rows_cap + 3][pitch_w] dwords of u8
+    blur_fused_any(image_of(img, img2, split, img_stride, blockIdx.z), out + (size_t)blockIdx.z * out_stride, W, H, w, h, bp, rows_cap, pitch_w,
+                   dword_ok, blockIdx.x, blockIdx.y, hrows);
 }
 
 static int fused_blur_rows(int H, int h, int ksize) { return (int)((FB_TH - 1) * ((double)H / h)) + (ksize | 1) + 4; }
+// LDS of a fused tile: rows x 64 f32 of horizontal-pass results, then the staged u8 rows (three rows of slack: the fast tile's
+// horizontal pass works on whole groups of four rows)
+static size_t fused_lds_bytes(int rows, int pitch_w) { return (size_t)rows * 256 + (size_t)(rows + 3) * 4 * pitch_w; }
 // dwords per staged source row: the columns 64 destination pixels need (63 scale + 1 + ksize), the 4-alignment slack and the word
 // blur_h4_stream reads ahead
 static int staged_pitch_words(int W, int w, int ksize) { return ((int)(63 * ((double)W / w)) + (ksize | 1) + 2 + 3) / 4 + 3; }
@@ -567,7 +690,7 @@ __global__ __launch_bounds__(256) void k_blur_multi(const uint8_t* __restrict__ 
     const int by = rem / J.gx, bx = rem - by * J.gx;
     const uint8_t* base = image_of(img, img2, split, img_stride, z);
     float* out = J.out + (size_t)z * J.out_stride;
-    if (J.fused) blur_fused_tile(base, out, W, H, J.w, J.h, J.bp, J.rows_cap, J.pitch_w, dword_ok, bx, by, hrows);
+    if (J.fused) blur_fused_any(base, out, W, H, J.w, J.h, J.bp, J.rows_cap, J.pitch_w, dword_ok, bx, by, hrows);
     else blur3_block(base, out, W, H, bx, by);
 }
 // Layer images of several layers of G frames in ONE launch.  jobs[i]: layer size, BlurParams, out / out_stride filled by the caller; a
@@ -591,9 +714,9 @@ void launch_blur_multi(hipStream_t st, const uint8_t* img, const uint8_t* img2, 
         if (J.fused) {
             J.rows_cap = fused_blur_rows(H, J.h, J.bp.ksize);
             const int pitch_w = staged_pitch_words(W, J.w, J.bp.ksize);
-            J.pitch_w = (size_t)J.rows_cap * (256 + 4 * pitch_w) <= 64 * 1024 ? pitch_w : 0;
+            J.pitch_w = fused_lds_bytes(J.rows_cap, pitch_w) <= 64 * 1024 ? pitch_w : 0;
             J.gx = (J.w + 63) / 64; J.gy = (J.h + FB_TH - 1) / FB_TH;
-            lds = std::max(lds, (size_t)J.rows_cap * (256 + 4 * J.pitch_w));
+            lds = std::max(lds, fused_lds_bytes(J.rows_cap, J.pitch_w));
         } else {
             J.rows_cap = J.pitch_w = 0;
             J.gx = (W / 4 + 63) / 64; J.gy = ((H + 3) / 4 + 3) / 4;
@@ -638,8 +761,8 @@ void launch_blur_resize(hipStream_t st, const uint8_t* img, const uint8_t* img2,
     const int pitch_w = staged_pitch_words(W, w, bp.ksize);
     if (!two_pass && blur_resize_is_fused(W, H, w, h, bp.ksize)) {
         const int rows = fused_blur_rows(H, h, bp.ksize);
-        const int pw = (size_t)rows * (256 + 4 * pitch_w) <= 64 * 1024 ? pitch_w : 0;       // both regions within 64 KB, or the direct form
-        hipLaunchKernelGGL(k_blur_resize_fused, dim3((w + 63) / 64, (h + FB_TH - 1) / FB_TH, G), dim3(256), (size_t)rows * (256 + 4 * pw), st, img,
+        const int pw = fused_lds_bytes(rows, pitch_w) <= 64 * 1024 ? pitch_w : 0;           // both regions within 64 KB, or the direct form
+        hipLaunchKernelGGL(k_blur_resize_fused, dim3((w + 63) / 64, (h + FB_TH - 1) / FB_TH, G), dim3(256), fused_lds_bytes(rows, pw), st, img,
                            img2, split, img_stride, W, H, w, h, bp, out, out_stride, rows, pw, dword_ok);
         return;
     }

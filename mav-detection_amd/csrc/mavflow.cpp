@@ -170,11 +170,27 @@ static bool prepare_poly(int n, double sigma, PolyCoef* pc)  // FarnebackPrepare
     return true;
 }
 
+// resize(INTER_LINEAR): source index and weight for destination index o of d along an axis of S source pixels -- the host twin of the
+// kernels' resize_coord (same expression, same roundings: this file is compiled without FMA contraction): (o + 0.5) * scale - 0.5 in
+// double, rounded to float, floor, clamp.
+static void resize_coord_host(int o, int S, int d, double scale, int* s0, float* f)
+{
+    if (d == S) { *s0 = o; *f = 0.f; return; }
+    const double p = (o + 0.5) * scale;
+    float t = (float)(p - 0.5);
+    int s = (int)floorf(t);
+    t -= (float)s;
+    if (s < 0) { t = 0.f; s = 0; }
+    if (s >= S - 1) { t = 0.f; s = S - 1; }
+    *s0 = s; *f = t;
+}
+
 // ---- context -------------------------------------------------------------------------------------------
 struct Layer {
     int w, h, ksize;
     double sigma;
     float* g = nullptr;      // device copy of the Gaussian taps (getGaussianKernel(ksize, sigma, CV_32F))
+    int* coord = nullptr;    // device: xs[w] | xf[w] | ys[h] | yf[h] -- the resize coordinates of the layer's columns and rows (coarse layers)
 };
 
 enum KernelId { K_BLUR_RESIZE, K_POLYEXP, K_UPDATE, K_ITER, K_ITER_COARSE, K_FOE, K_PHI, K_MISC, K_COUNT };
@@ -312,7 +328,8 @@ struct ProfScope {
 static void free_layer(Layer& l)
 {
     if (l.g) hipFree(l.g);
-    l.g = nullptr;
+    if (l.coord) hipFree(l.coord);
+    l.g = nullptr; l.coord = nullptr;
 }
 
 // Pairs of the largest group the small-group schedule can take (is_small_group) when the context runs groups of `group` pairs.
@@ -472,6 +489,13 @@ extern "C" int mav_create(mav_ctx** out, int device, int W, int H, int max_batch
         gaussian_kernel(l.ksize, l.sigma, g);
         HIPB(hipMalloc(&l.g, g.size() * sizeof(float)));
         HIPB(hipMemcpy(l.g, g.data(), g.size() * sizeof(float), hipMemcpyHostToDevice));
+        if (k > 0) {                                    // the layer's resize coordinates, once (the kernels used to evaluate them per thread, in double)
+            std::vector<int> tab(2 * (size_t)(l.w + l.h));
+            for (int x = 0; x < l.w; x++) resize_coord_host(x, W, l.w, (double)W / l.w, &tab[x], (float*)&tab[l.w + x]);
+            for (int y = 0; y < l.h; y++) resize_coord_host(y, H, l.h, (double)H / l.h, &tab[2 * l.w + y], (float*)&tab[2 * l.w + l.h + y]);
+            HIPB(hipMalloc(&l.coord, tab.size() * sizeof(int)));
+            HIPB(hipMemcpy(l.coord, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+        }
     }
     c->n0 = (size_t)W * H;
     c->n1 = levels >= 1 ? (size_t)c->layers[1].w * c->layers[1].h : 0;
@@ -813,7 +837,12 @@ static int check_launch(const char* what)
 // ---- Farneback: the schedule of one group of pairs --------------------------------------------------------------------
 static BlurParams blur_of(const mav_ctx* c, const Layer& l)
 {
-    return BlurParams{l.ksize, (l.ksize == 3 && l.sigma <= 0) ? 1 : 0, l.g, (double)c->W / l.w, (double)c->H / l.h};
+    BlurParams bp{l.ksize, (l.ksize == 3 && l.sigma <= 0) ? 1 : 0, l.g, (double)c->W / l.w, (double)c->H / l.h, nullptr, nullptr, nullptr, nullptr};
+    if (l.coord) {
+        bp.xs = l.coord; bp.xf = (const float*)(l.coord + l.w);
+        bp.ys = l.coord + 2 * l.w; bp.yf = (const float*)(l.coord + 2 * l.w + l.h);
+    }
+    return bp;
 }
 
 // How the sweeps of layer k run for a group of g pairs (plan_sweeps decides, layer_sweeps executes, mav_schedule_info reports).

@@ -24,6 +24,10 @@ struct BlurParams {
     const float* g;      // [ksize]
     double scale_x;      // W / w
     double scale_y;      // H / h
+    // resize(INTER_LINEAR) coordinates of the layer's w columns and h rows as tables (device memory; built once per context by the host
+    // in resize_coord's own arithmetic): source index and weight of the right / lower neighbour.  nullptr: evaluated in the kernel.
+    const int* xs; const float* xf;      // [w]
+    const int* ys; const float* yf;      // [h]
 };
 
 // How the detection kernels treat one pair's float32 flow (what numpy does with it in the reference):
