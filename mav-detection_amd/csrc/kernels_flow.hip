@@ -512,7 +512,7 @@ static __device__ __forceinline__ float blur_v1_interior(const float* __restrict
     for (int t = 0; t < KS; t++) { const float g = bp.g[t]; b0 = fmaf(g, px[t], b0); b1 = fmaf(g, px[t + 1], b1); }
     return fmaf(b1, f, b0 * (1.f - f));
 }
-template <int KS>
+template <int KS, int TH>
 static __device__ __forceinline__ void blur_fused_tile_fast(const uint8_t* __restrict__ base, float* __restrict__ out, int W, int H, int w, int h,
                                                             const BlurParams& bp, int rows_cap, int pitch_w, int tile_x, int tile_y,
                                                             float* __restrict__ hrows)
@@ -520,18 +520,18 @@ static __device__ __forceinline__ void blur_fused_tile_fast(const uint8_t* __res
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     constexpr int r = KS >> 1;
     const int dx = tile_x * 64 + lane, dxc = min(dx, w - 1);
-    const int dy0 = tile_y * FB_TH, dy1 = min(dy0 + FB_TH, h) - 1;
-    const int dyc = min(dy0 + (lane & (FB_TH - 1)), h - 1);
+    const int dy0 = tile_y * TH, dy1 = min(dy0 + TH, h) - 1;
+    const int dyc = min(dy0 + (lane & (TH - 1)), h - 1);
     const int s0 = bp.xs[dxc];
     const float f = bp.xf[dxc];
-    const int row_s = bp.ys[dyc];                                           // lane L < 16: source row / weight of destination row dy0 + L
+    const int row_s = bp.ys[dyc];                                           // lane L < TH: source row / weight of destination row dy0 + L
     const float row_f = bp.yf[dyc];
     int xb, words;
     tile_columns(s0, bp, &xb, &words);
     words = min(words, pitch_w);
     const int off = s0 - r - xb;
     uint32_t* sw = (uint32_t*)(hrows + rows_cap * 64);
-    const int sa = __builtin_amdgcn_readlane(row_s, 0), sb = __builtin_amdgcn_readlane(row_s, FB_TH - 1);
+    const int sa = __builtin_amdgcn_readlane(row_s, 0), sb = __builtin_amdgcn_readlane(row_s, TH - 1);
     const int ylo = max(sa - r, 0), yhi = min(sb + 1 + r, H - 1);
     const int n_rows = min(yhi - ylo + 1, rows_cap);
     // ---- stage the u8 source rows [ylo, ylo + n_rows), byte columns [xb, xb + 4 words)
@@ -585,7 +585,7 @@ static __device__ __forceinline__ void blur_fused_tile_fast(const uint8_t* __res
     const float* col = hrows + lane - ylo * 64;
     const bool interior = sa - r >= 0 && sb + 1 + r < H;                    // wave-uniform: no row of the tile touches the border
 #pragma unroll
-    for (int j = 0; j < FB_TH / 4; j++) {
+    for (int j = 0; j < TH / 4; j++) {
         const int dy = dy0 + j * 4 + wv;                                     // wave-uniform
         if (dy > dy1) break;
         const int t0 = __builtin_amdgcn_readlane(row_s, j * 4 + wv);
@@ -600,31 +600,53 @@ static __host__ __device__ __forceinline__ bool fused_fast_ok(const BlurParams& 
     return dword_ok && pitch_w > 0 && bp.xs != nullptr && (bp.ksize == 5 || bp.ksize == 13);
 }
 static __device__ __forceinline__ void blur_fused_any(const uint8_t* __restrict__ base, float* __restrict__ out, int W, int H, int w, int h,
-                                                      const BlurParams& bp, int rows_cap, int pitch_w, int dword_ok, int tile_x, int tile_y,
+                                                      const BlurParams& bp, int rows_cap, int pitch_w, int dword_ok, int th, int tile_x, int tile_y,
                                                       float* __restrict__ hrows)
 {
+    // th = tile height chosen by the host (fused_plan): 16, or 8 where 16 rows' source region does not fit LDS (fast tile only)
     if (fused_fast_ok(bp, pitch_w, dword_ok)) {
-        if (bp.ksize == 5) blur_fused_tile_fast<5>(base, out, W, H, w, h, bp, rows_cap, pitch_w, tile_x, tile_y, hrows);
-        else blur_fused_tile_fast<13>(base, out, W, H, w, h, bp, rows_cap, pitch_w, tile_x, tile_y, hrows);
+        if (bp.ksize == 5) {
+            if (th == 16) blur_fused_tile_fast<5, 16>(base, out, W, H, w, h, bp, rows_cap, pitch_w, tile_x, tile_y, hrows);
+            else blur_fused_tile_fast<5, 8>(base, out, W, H, w, h, bp, rows_cap, pitch_w, tile_x, tile_y, hrows);
+        } else {
+            if (th == 16) blur_fused_tile_fast<13, 16>(base, out, W, H, w, h, bp, rows_cap, pitch_w, tile_x, tile_y, hrows);
+            else blur_fused_tile_fast<13, 8>(base, out, W, H, w, h, bp, rows_cap, pitch_w, tile_x, tile_y, hrows);
+        }
     } else
         blur_fused_tile(base, out, W, H, w, h, bp, rows_cap, pitch_w, dword_ok, tile_x, tile_y, hrows);
 }
 __global__ __launch_bounds__(256) void k_blur_resize_fused(const uint8_t* __restrict__ img, const uint8_t* __restrict__ img2, int split,
                                                            size_t img_stride, int W, int H, int w, int h, BlurParams bp,
-                                                           float* __restrict__ out, size_t out_stride, int rows_cap, int pitch_w, int dword_ok)
+                                                           float* __restrict__ out, size_t out_stride, int rows_cap, int pitch_w, int dword_ok, int th)
 {
     extern __shared__ __attribute__((aligned(16))) float hrows[];       // [rows_cap][64] f32, then [rows_cap + 3][pitch_w] dwords of u8
     blur_fused_any(image_of(img, img2, split, img_stride, blockIdx.z), out + (size_t)blockIdx.z * out_stride, W, H, w, h, bp, rows_cap, pitch_w,
-                   dword_ok, blockIdx.x, blockIdx.y, hrows);
+                   dword_ok, th, blockIdx.x, blockIdx.y, hrows);
 }
 
-static int fused_blur_rows(int H, int h, int ksize) { return (int)((FB_TH - 1) * ((double)H / h)) + (ksize | 1) + 4; }
+static int fused_blur_rows(int H, int h, int ksize, int th = FB_TH) { return (int)((th - 1) * ((double)H / h)) + (ksize | 1) + 4; }
 // LDS of a fused tile: rows x 64 f32 of horizontal-pass results, then the staged u8 rows (three rows of slack: the fast tile's
 // horizontal pass works on whole groups of four rows)
 static size_t fused_lds_bytes(int rows, int pitch_w) { return (size_t)rows * 256 + (size_t)(rows + 3) * 4 * pitch_w; }
 // dwords per staged source row: the columns 64 destination pixels need (63 scale + 1 + ksize), the 4-alignment slack and the word
 // blur_h4_stream reads ahead
 static int staged_pitch_words(int W, int w, int ksize) { return ((int)(63 * ((double)W / w)) + (ksize | 1) + 2 + 3) / 4 + 3; }
+// How a fused layer's tiles are cut: 64 x 16 with the source region staged in LDS when that fits 64 KB; else, for the fast tile
+// (fused_fast_ok), 64 x 8 staged (layer 2 of the 4K / 5-layer preset: 13 taps at scale 6.25 -- 110 source rows of 420 bytes for 16
+// destination rows); else 64 x 16 unstaged (every thread reads its bytes from global memory).
+struct FusedPlan { int th, rows, pitch_w; size_t lds; };
+static FusedPlan fused_plan(int W, int H, int w, int h, const BlurParams& bp, int dword_ok)
+{
+    const int pitch = staged_pitch_words(W, w, bp.ksize);
+    FusedPlan p{FB_TH, fused_blur_rows(H, h, bp.ksize), pitch, 0};
+    if (fused_lds_bytes(p.rows, pitch) > 64 * 1024) {
+        const int rows8 = fused_blur_rows(H, h, bp.ksize, 8);
+        if (fused_fast_ok(bp, pitch, dword_ok) && fused_lds_bytes(rows8, pitch) <= 64 * 1024) { p.th = 8; p.rows = rows8; }
+        else p.pitch_w = 0;
+    }
+    p.lds = fused_lds_bytes(p.rows, p.pitch_w);
+    return p;
+}
 bool blur_resize_is_fused(int W, int H, int w, int h, int ksize)
 {
     return !(w == W && h == H) && ksize <= 13 && H > 2 * ksize && W > 2 * ksize && (size_t)fused_blur_rows(H, h, ksize) * 256 <= 48 * 1024;
@@ -690,7 +712,7 @@ __global__ __launch_bounds__(256) void k_blur_multi(const uint8_t* __restrict__ 
     const int by = rem / J.gx, bx = rem - by * J.gx;
     const uint8_t* base = image_of(img, img2, split, img_stride, z);
     float* out = J.out + (size_t)z * J.out_stride;
-    if (J.fused) blur_fused_any(base, out, W, H, J.w, J.h, J.bp, J.rows_cap, J.pitch_w, dword_ok, bx, by, hrows);
+    if (J.fused) blur_fused_any(base, out, W, H, J.w, J.h, J.bp, J.rows_cap, J.pitch_w, dword_ok, J.th, bx, by, hrows);
     else blur3_block(base, out, W, H, bx, by);
 }
 // Layer images of several layers of G frames in ONE launch.  jobs[i]: layer size, BlurParams, out / out_stride filled by the caller; a
@@ -712,11 +734,10 @@ void launch_blur_multi(hipStream_t st, const uint8_t* img, const uint8_t* img2, 
         BlurJob& J = jobs.j[i];
         J.fused = !(J.w == W && J.h == H);
         if (J.fused) {
-            J.rows_cap = fused_blur_rows(H, J.h, J.bp.ksize);
-            const int pitch_w = staged_pitch_words(W, J.w, J.bp.ksize);
-            J.pitch_w = fused_lds_bytes(J.rows_cap, pitch_w) <= 64 * 1024 ? pitch_w : 0;
-            J.gx = (J.w + 63) / 64; J.gy = (J.h + FB_TH - 1) / FB_TH;
-            lds = std::max(lds, fused_lds_bytes(J.rows_cap, J.pitch_w));
+            const FusedPlan fp = fused_plan(W, H, J.w, J.h, J.bp, dword_ok);
+            J.rows_cap = fp.rows; J.pitch_w = fp.pitch_w; J.th = fp.th;
+            J.gx = (J.w + 63) / 64; J.gy = (J.h + fp.th - 1) / fp.th;
+            lds = std::max(lds, fp.lds);
         } else {
             J.rows_cap = J.pitch_w = 0;
             J.gx = (W / 4 + 63) / 64; J.gy = ((H + 3) / 4 + 3) / 4;
@@ -760,10 +781,9 @@ void launch_blur_resize(hipStream_t st, const uint8_t* img, const uint8_t* img2,
     const int dword_ok = (W % 4 == 0 && img_stride % 4 == 0 && ((uintptr_t)img & 3) == 0 && ((uintptr_t)img2 & 3) == 0) ? 1 : 0;
     const int pitch_w = staged_pitch_words(W, w, bp.ksize);
     if (!two_pass && blur_resize_is_fused(W, H, w, h, bp.ksize)) {
-        const int rows = fused_blur_rows(H, h, bp.ksize);
-        const int pw = fused_lds_bytes(rows, pitch_w) <= 64 * 1024 ? pitch_w : 0;           // both regions within 64 KB, or the direct form
-        hipLaunchKernelGGL(k_blur_resize_fused, dim3((w + 63) / 64, (h + FB_TH - 1) / FB_TH, G), dim3(256), fused_lds_bytes(rows, pw), st, img,
-                           img2, split, img_stride, W, H, w, h, bp, out, out_stride, rows, pw, dword_ok);
+        const FusedPlan fp = fused_plan(W, H, w, h, bp, dword_ok);
+        hipLaunchKernelGGL(k_blur_resize_fused, dim3((w + 63) / 64, (h + fp.th - 1) / fp.th, G), dim3(256), fp.lds, st, img,
+                           img2, split, img_stride, W, H, w, h, bp, out, out_stride, fp.rows, fp.pitch_w, dword_ok, fp.th);
         return;
     }
     int rows_blk = 16;

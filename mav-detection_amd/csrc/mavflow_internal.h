@@ -44,7 +44,7 @@ struct DerotParams {  // one pair; Detector.derotate
 #define MAV_MAX_JOBS 6
 struct PolyJob { const float* I; float* R; size_t I_stride, R_stride; int w, h, tiles_x, per_img, first_block, pad; };
 struct PolyJobs { int n, pad; PolyJob j[MAV_MAX_JOBS]; };
-struct BlurJob { float* out; size_t out_stride; BlurParams bp; int w, h, fused, gx, gy, first_block, rows_cap, pitch_w; };
+struct BlurJob { float* out; size_t out_stride; BlurParams bp; int w, h, fused, gx, gy, first_block, rows_cap, pitch_w, th, pad; };
 struct BlurJobs { int n, pad; BlurJob j[MAV_MAX_JOBS]; };
 
 // ---- flow kernels (kernels_flow.hip) ----------------------------------------------------------------------
