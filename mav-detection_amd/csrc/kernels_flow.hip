@@ -260,6 +260,62 @@ static __device__ __forceinline__ void blur_h4_stream(WordFn rd, int off, float 
     else blur_h4_stream_t<0>(rd, off, f, bp, out);
 }
 
+// The horizontal pass once more, for LONG Gaussians (the two-pass kernels: 37 and 95 taps at 3840 x 2160 / 5 layers), on tap PAIRS
+// kept in LDS.  blur_h4_stream's generic loop fetched every tap with a vector load from global memory and waited for it -- one
+// memory round trip per tap (the taps sit behind a pointer the compiler cannot prove constant next to the kernel's own stores) --
+// and shuffled registers to pack two rows into one v_pk_fma_f32.  Here the (b0, b1) accumulators of ONE row are the packed pair:
+// source byte t of the row contributes  g[t] * p  to B[s0]  and  g[t - 1] * p  to B[s0 + 1], i.e. one packed FMA of the pair
+// G2[t] = (g[t], g[t - 1]) (LDS, one broadcast ds_read_b64 per tap for all four rows) with the splat (p, p):
+//     B[s0]     accumulates g[0] p[0], g[1] p[1], ...            -- the order of blur_h4 / blur_h4_stream
+//     B[s0 + 1] accumulates g[0] p[1], g[1] p[2], ...            -- likewise
+// G2[0] = (g[0], 0), G2[ksize] = (0, g[ksize - 1]) and the padding up to a multiple of four taps is (0, 0): a fused multiply-add
+// with a zero tap returns its accumulator unchanged (pixels are finite, the accumulators start at +0), so the bits are those of the
+// other forms (tests/test_gpu_flow.py: fused == two-pass == oracle).
+typedef float mav_f2 __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ int tap_pairs_padded(int ksize) { return (ksize + 1 + 3) & ~3; }
+static __device__ __forceinline__ void stage_tap_pairs(const BlurParams& bp, mav_f2* __restrict__ G2)
+{
+    const int n = tap_pairs_padded(bp.ksize);
+    for (int t = threadIdx.x; t < n; t += blockDim.x) {
+        mav_f2 v;
+        v.x = t < bp.ksize ? bp.g[t] : 0.f;
+        v.y = (t >= 1 && t <= bp.ksize) ? bp.g[t - 1] : 0.f;
+        G2[t] = v;
+    }
+}
+template <typename WordFn>
+static __device__ __forceinline__ void blur_h4_pairs(WordFn rd, int off, float f, int ksize, const mav_f2* __restrict__ G2, float out[4])
+{
+    const int w0 = off >> 2;
+    const unsigned sh = (unsigned)(off & 3);
+    const int n_words = tap_pairs_padded(ksize) >> 2;
+    mav_f2 acc[4];
+    uint32_t lo[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { acc[k] = (mav_f2)(0.f, 0.f); lo[k] = rd(k, w0); }
+    for (int c = 0; c < n_words; c++) {
+        uint32_t cur[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t hi = rd(k, w0 + c + 1);              // (one word of slack behind every staged row)
+            cur[k] = __builtin_amdgcn_alignbyte(hi, lo[k], sh);
+            lo[k] = hi;
+        }
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const mav_f2 G = G2[4 * c + b];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float p = (float)((cur[k] >> (8 * b)) & 0xffu);
+                acc[k] = __builtin_elementwise_fma(G, (mav_f2)(p, p), acc[k]);
+            }
+        }
+    }
+    const float a0 = 1.f - f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[k] = fmaf(acc[k].y, f, acc[k].x * a0);
+}
+
 // Source rows [y0, y0 + n_rows) (row index clamped to the image), byte columns [xb, xb + 4 words) of one image -> LDS, row pitch
 // pitch_w dwords; xb is a multiple of 4 (possibly negative).  Columns outside the image hold their BORDER_REFLECT_101 pixels.
 // Dword-addressable rows: coalesced dword loads; frames whose width is no multiple of 4: byte by byte.
@@ -379,13 +435,16 @@ __global__ __launch_bounds__(256) void k_blur_resize_h(const uint8_t* __restrict
                                                        size_t img_stride, int W, int H, int w, BlurParams bp,
                                                        float* __restrict__ tmp, size_t tmp_stride, int rows_blk, int pitch_w, int dword_ok)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t srows[];         // [rows_blk][pitch_w]
+    extern __shared__ __attribute__((aligned(16))) uint32_t srows[];         // [rows_blk][pitch_w], then the tap pairs (stage_tap_pairs)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int dx0 = blockIdx.x * 64;
     const uint8_t* base = image_of(img, img2, split, img_stride, blockIdx.z);
     const int dx = dx0 + lane;
+    mav_f2* G2 = (mav_f2*)(srows + ((rows_blk * pitch_w + 1) & ~1));
+    stage_tap_pairs(bp, G2);                                                 // (visible after the first barrier below)
     int s0; float f;
-    resize_coord(min(dx, w - 1), W, w, bp.scale_x, &s0, &f);
+    if (bp.xs) { s0 = bp.xs[min(dx, w - 1)]; f = bp.xf[min(dx, w - 1)]; }
+    else resize_coord(min(dx, w - 1), W, w, bp.scale_x, &s0, &f);
     int xb, words;
     tile_columns(s0, bp, &xb, &words);
     const int off = s0 - (bp.ksize >> 1) - xb;
@@ -399,7 +458,7 @@ __global__ __launch_bounds__(256) void k_blur_resize_h(const uint8_t* __restrict
         __syncthreads();
         for (int i = wv * 4; i < n_rows; i += 16) {
             float o[4];
-            blur_h4_stream([&](int k, int wi) { return srows[min(i + k, n_rows - 1) * pitch_w + wi]; }, off, f, bp, o);
+            blur_h4_pairs([&](int k, int wi) { return srows[min(i + k, n_rows - 1) * pitch_w + wi]; }, off, f, bp.ksize, G2, o);
             if (dx < w) {
 #pragma unroll
                 for (int k = 0; k < 4; k++)
@@ -792,7 +851,8 @@ void launch_blur_resize(hipStream_t st, const uint8_t* img, const uint8_t* img2,
     {
         const int gx = (w + 63) / 64, nby = (H + rows_blk - 1) / rows_blk;
         const int gy = nby;                                               // one row block per workgroup (walking several measured slower: 69 vs 47 us)
-        hipLaunchKernelGGL(k_blur_resize_h, dim3(gx, gy, G), dim3(256), (size_t)rows_blk * pitch_w * 4, st, img,
+        const size_t lds_h = (size_t)((rows_blk * pitch_w + 1) & ~1) * 4 + (size_t)((bp.ksize + 4) & ~3) * 8;    // staged rows + tap pairs
+        hipLaunchKernelGGL(k_blur_resize_h, dim3(gx, gy, G), dim3(256), lds_h, st, img,
                            img2, split, img_stride, W, H, w, bp, tmp, tmp_stride, rows_blk, pitch_w, dword_ok);
     }
     else
