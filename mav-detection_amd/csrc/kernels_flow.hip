@@ -319,6 +319,7 @@ static __device__ __forceinline__ void blur_h4_pairs(WordFn rd, int off, float f
 // Source rows [y0, y0 + n_rows) (row index clamped to the image), byte columns [xb, xb + 4 words) of one image -> LDS, row pitch
 // pitch_w dwords; xb is a multiple of 4 (possibly negative).  Columns outside the image hold their BORDER_REFLECT_101 pixels.
 // Dword-addressable rows: coalesced dword loads; frames whose width is no multiple of 4: byte by byte.
+template <int NB = 8>      // NB loads of a thread in flight before the first LDS store
 static __device__ __forceinline__ void stage_rows(const uint8_t* __restrict__ base, int W, int H, int y0, int n_rows, int xb, int words,
                                                   bool dword_ok, uint32_t* __restrict__ sw, int pitch_w)
 {
@@ -332,11 +333,11 @@ static __device__ __forceinline__ void stage_rows(const uint8_t* __restrict__ ba
         const int n_left = 4 * wlo, n_out = n_left + 4 * max(words - whi, 0);
         const int n_chunks = (whi - wlo + 63) >> 6, rows_w = n_rows > wv ? (n_rows - wv + 3) >> 2 : 0;
         const int n_items = rows_w * n_chunks;
-        for (int it0 = 0; it0 < n_items; it0 += 8) {
-            uint32_t v[8];
-            int dst[8];
+        for (int it0 = 0; it0 < n_items; it0 += NB) {
+            uint32_t v[NB];
+            int dst[NB];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < NB; u++) {
                 const int it = it0 + u;
                 const int ri = n_chunks == 1 ? it : it / n_chunks, ch = it - ri * n_chunks;
                 const int row = wv + 4 * ri, wd = wlo + 64 * ch + lane;
@@ -346,7 +347,7 @@ static __device__ __forceinline__ void stage_rows(const uint8_t* __restrict__ ba
                 v[u] = g[ok ? wd : wlo];
             }
 #pragma unroll
-            for (int u = 0; u < 8; u++)
+            for (int u = 0; u < NB; u++)
                 if (dst[u] >= 0) sw[dst[u]] = v[u];
         }
         if (n_out > 0)
@@ -454,7 +455,9 @@ __global__ __launch_bounds__(256) void k_blur_resize_h(const uint8_t* __restrict
         const int y0 = yb * rows_blk;
         const int n_rows = min(rows_blk, H - y0);
         if (yb != (int)blockIdx.y) __syncthreads();             // everybody has finished reading the previous block's rows
-        stage_rows(base, W, H, y0, n_rows, xb, min(words, pitch_w), dword_ok != 0, srows, pitch_w);
+        // (a workgroup's life here is: stage 16 rows -> barrier -> one pass of arithmetic -> store, with LDS allowing 3 - 8 workgroups
+        // per CU: the staging round trips are its critical path, so 24 loads per thread go out before the first LDS store)
+        stage_rows<24>(base, W, H, y0, n_rows, xb, min(words, pitch_w), dword_ok != 0, srows, pitch_w);
         __syncthreads();
         for (int i = wv * 4; i < n_rows; i += 16) {
             float o[4];
