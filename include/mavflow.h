@@ -248,6 +248,10 @@ int mav_profile_get(mav_ctx*, int* n, const char** names, double* total_ms, long
  * them) was running in the profiled calls: the union of the launches' intervals.  With two pairs in flight (option
  * "pairs_in_flight") launches of one class overlap and their summed durations exceed the wall time. */
 int mav_profile_busy(mav_ctx*, const char* names, double* busy_ms);
+/* The profiled launches (mode 1) or runs of launches (mode 2) themselves, as intervals: class index in mav_profile_get's order, stream
+ * (0 = the context's stream, 1 = its second compute stream), start / end in ms since mav_profile_enable.  *n = capacity in, count out;
+ * with NULL arrays *n returns the number of intervals.  tools/untraced_anatomy.py builds the step's timeline from it without a tracer. */
+int mav_profile_intervals(mav_ctx*, int* n, int* kernel_class, int* stream, float* t0_ms, float* t1_ms);
 
 /* Calibration for the roofline record: GB/s this GPU delivers, now, to a plain streaming kernel with the sweep kernel's mix of
  * 3 reads : 1 write (four temporary buffers of bytes_per_buffer each, float4 per thread, `reps` timed launches on the context's

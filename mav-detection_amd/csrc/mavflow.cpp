@@ -196,8 +196,8 @@ struct Layer {
 enum KernelId { K_BLUR_RESIZE, K_POLYEXP, K_UPDATE, K_ITER, K_ITER_COARSE, K_FOE, K_PHI, K_MISC, K_COUNT };
 static const char* const kKernelNames[K_COUNT] = {"blur_resize", "polyexp", "update_matrices", "blur_iter", "blur_iter_coarse",
                                                   "foe_ransac", "phi_mask_box", "misc"};
-struct ProfRec { int kid; hipEvent_t a, b; };
-struct ProfInterval { int kid; float t0, t1; };      // ms since the profile was switched on
+struct ProfRec { int kid; hipEvent_t a, b; int stream; };
+struct ProfInterval { int kid; float t0, t1; int stream; };      // ms since the profile was switched on
 
 struct mav_ctx {
     int device = 0, W = 0, H = 0, max_batch = 0, group = 0, group_fine = 1;
@@ -295,7 +295,7 @@ static void close_run(mav_ctx* c, size_t i)
     hipEvent_t b = nullptr;
     hipEventCreate(&b);
     hipEventRecord(b, r.st);
-    c->prof.push_back({r.kid, r.a, b});
+    c->prof.push_back({r.kid, r.a, b, r.st == c->stream ? 0 : 1});
     c->open_runs.erase(c->open_runs.begin() + i);
 }
 static void prof_close_stream(mav_ctx* c, hipStream_t st)       // before a stream waits for another one: the wait is not part of the run
@@ -321,7 +321,7 @@ struct ProfScope {
     }
     ~ProfScope()
     {
-        if (c->profiling == 1) { hipEventRecord(b, st); c->prof.push_back({kid, a, b}); }
+        if (c->profiling == 1) { hipEventRecord(b, st); c->prof.push_back({kid, a, b, st == c->stream ? 0 : 1}); }
     }
 };
 
@@ -739,7 +739,7 @@ static int prof_collect(mav_ctx* c)
         float ms = 0, t0 = 0;
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
             c->prof_ms[r.kid] += ms; c->prof_n[r.kid]++;
-            if (c->prof_base && hipEventElapsedTime(&t0, c->prof_base, r.a) == hipSuccess) c->prof_iv.push_back({r.kid, t0, t0 + ms});
+            if (c->prof_base && hipEventElapsedTime(&t0, c->prof_base, r.a) == hipSuccess) c->prof_iv.push_back({r.kid, t0, t0 + ms, r.stream});
         }
         hipEventDestroy(r.a); hipEventDestroy(r.b);
     }
@@ -786,6 +786,22 @@ extern "C" int mav_profile_busy(mav_ctx* c, const char* names, double* busy_ms)
     }
     if (hi >= lo) busy += hi - lo;
     *busy_ms = busy;
+    return MAV_OK;
+}
+// Every profiled launch (mode 1) or run of launches (mode 2) since mav_profile_enable as an interval: class index (order of
+// mav_profile_get), stream (0 = the context's stream, 1 = its second compute stream), start / end in ms since the profile was switched
+// on.  *n: capacity in, count out (the total when the arrays are NULL).
+extern "C" int mav_profile_intervals(mav_ctx* c, int* n, int* kernel_class, int* stream, float* t0_ms, float* t1_ms)
+{
+    if (!c || !n) return fail(MAV_ERR_ARG, "mav_profile_intervals: NULL argument");
+    CHK(prof_collect(c));
+    const int total = (int)c->prof_iv.size();
+    if (!kernel_class || !stream || !t0_ms || !t1_ms) { *n = total; return MAV_OK; }
+    const int k = total < *n ? total : *n;
+    for (int i = 0; i < k; i++) {
+        kernel_class[i] = c->prof_iv[i].kid; stream[i] = c->prof_iv[i].stream; t0_ms[i] = c->prof_iv[i].t0; t1_ms[i] = c->prof_iv[i].t1;
+    }
+    *n = k;
     return MAV_OK;
 }
 extern "C" int mav_profile_get(mav_ctx* c, int* n, const char** names, double* total_ms, long* launches)

@@ -50,7 +50,7 @@ EXPORTS = [
     "mav_analyze_pyramid", "mav_pyramid_levels", "mav_pyramid_dims", "mav_optimize_window", "mav_stage_pyramid_level",
     "mav_detect", "mav_detect_dev", "mav_last_flow_dev", "mav_foe_dense_f32", "mav_phi_mask_f32", "mav_stage_coefficients",
     "mav_stage_phi_mask", "mav_last_masks_tpr_fpr", "mav_get_option", "mav_schedule_info", "mav_stage_blur_resize_two_pass",
-    "mav_membw_probe", "mav_runtime_info", "mav_upload_async_unordered", "mav_mem_info",
+    "mav_membw_probe", "mav_runtime_info", "mav_upload_async_unordered", "mav_mem_info", "mav_profile_intervals",
 ]
 
 _lib = None
@@ -132,6 +132,7 @@ def load(path: str | None = None) -> C.CDLL:
     lib.mav_profile_enable.argtypes = [vp, C.c_int]
     lib.mav_profile_get.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_long)]
     lib.mav_profile_busy.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double)]
+    lib.mav_profile_intervals.argtypes = [vp, C.POINTER(C.c_int), vp, vp, vp, vp]
     lib.mav_comm_unique_id.argtypes = [vp]
     lib.mav_comm_init.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
     lib.mav_comm_destroy.argtypes = [vp]
@@ -640,6 +641,16 @@ class Context:
         cnt = (C.c_long * 16)()
         check(self.lib.mav_profile_get(self.h, C.byref(n), names, ms, cnt))
         return {names[i].decode(): (ms[i], cnt[i]) for i in range(n.value)}
+
+    def profile_intervals(self):
+        """(class index, stream, t0 ms, t1 ms) arrays of every profiled launch / run since profile_enable; class names in
+        profile_get()'s order."""
+        n = C.c_int(0)
+        check(self.lib.mav_profile_intervals(self.h, C.byref(n), None, None, None, None))
+        k, st = np.empty(n.value, np.int32), np.empty(n.value, np.int32)
+        t0, t1 = np.empty(n.value, np.float32), np.empty(n.value, np.float32)
+        check(self.lib.mav_profile_intervals(self.h, C.byref(n), _ptr(k), _ptr(st), _ptr(t0), _ptr(t1)))
+        return k[:n.value], st[:n.value], t0[:n.value], t1[:n.value]
 
     def profile_busy(self, *names: str) -> float:
         """ms during which at least one launch of the named kernel classes was running (union of the launches' intervals)."""
