@@ -354,7 +354,7 @@ def test_options_are_reported_and_validated(mav):
         assert info["layers"][1]["blur"] == "fused" and info["layers"][1]["pairs_per_launch"] == 4
         for name, v in (("band_mb", 40), ("coarse_half", 3), ("strip", 20), ("phi_yloop", 4), ("phi_screen", 0), ("share_m", 0),
                         ("coarse_cache_mb", 100), ("bands", 3), ("group_fine", 2), ("small_batch", 0), ("sweep_write_through", 1),
-                        ("deep_batch", 0), ("coarse_bands", 1)):
+                        ("deep_batch", 0), ("coarse_bands", 1), ("band_phase", 0)):
             c.set_option(name, v)
             assert c.get_option(name) == v
             assert c.schedule_info(64)[name] == v
@@ -498,6 +498,16 @@ def test_deep_layers_once_per_call_and_banded_coarse_layers_are_bit_identical(ma
             assert np.array_equal(c.farneback_sequence(seq), seq_ref), (deep, cb)
             assert np.array_equal(c.farneback(prev[:1], nxt[:1]), ref[:1])
             assert np.array_equal(c.farneback(prev[:group + 1], nxt[:group + 1]), ref[:group + 1])
+        # "band_phase": the second stream's pairs on a partition shifted by half a band (J + 1 bands, the outer two of half size), so that
+        # one stream's initial-M launches fall into the other's sweeps; with band_mb = 8 the finest layer has up to 5 bands of 12 tile rows
+        for bp, mb in ((0, band_mb), (1, band_mb), (1, max(band_mb, 20)), (3, band_mb)):
+            c.set_option("band_phase", bp)
+            c.set_option("band_mb", mb)
+            for rep in range(2):
+                out = c.farneback(prev, nxt)
+                assert np.array_equal(out, ref), ("band_phase", bp, mb, rep, int((out != ref).sum()))
+        c.set_option("band_mb", band_mb)
+        c.set_option("band_phase", 1)
         two = c.process_batch(prev, nxt, smp)
         for key in ("flow", "mask_fixed", "mask_dyn"):
             assert np.array_equal(two[key], chain[key]), key
