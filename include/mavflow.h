@@ -100,9 +100,9 @@ int mav_device_count(void);       /* <= 0 when no GPU is visible */
  *                      up to 64 pairs of the call before the groups start, instead of once per group
  *   "coarse_bands"     default 0: 1 = a coarse layer whose per-pair working set exceeds "band_mb" (layer 1 of the 4K preset, 106 MB) is
  *                      swept like the finest layer, pairs alternating between the two streams band by band (measured slower: off)
- *   "band_phase"       n > 0 (default 2): in the two-stream schedule the pairs of the second stream use a band partition shifted by half a
+ *   "band_phase"       default 0; n > 0: in the two-stream schedule the pairs of the second stream use a band partition shifted by half a
  *                      band whenever a pair has at least n bands, so that the two streams do not build their bands' initial M (HBM-bound)
- *                      at the same moments; 0 = the same partition on both streams
+ *                      at the same moments (measured slower: the lockstep of the two streams protects the Infinity Cache)
  *   "sweep_write_through"  -1 (default): the sweeps' M' stores are write-through (sc1) in the two-stream schedules, plain otherwise;
  *                      0 / 1: never / always
  *   "strip"            width in tiles of the column strips of the XCD-aware tile order (0 = automatic)

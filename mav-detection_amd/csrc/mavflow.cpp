@@ -231,8 +231,8 @@ struct mav_ctx {
     struct DeepSet { float *I = nullptr, *R = nullptr, *Ma = nullptr, *Mb = nullptr, *f[2] = {nullptr, nullptr}; } deep;
     int kd = 0, deep_cap = 0;                 // kd = 0: no deep layer
     bool deep_batch = true;                   // option "deep_batch"
-    int band_phase = 2;                       // option "band_phase": n > 0 = the second stream's pairs use a partition shifted by half a band
-                                              // when a pair has at least n bands (sweeps_band_major); 0 = never
+    int band_phase = 0;                       // option "band_phase": n > 0 = the second stream's pairs use a partition shifted by half a band
+                                              // when a pair has at least n bands (sweeps_band_major); 0 = never (default: measured slower)
     bool coarse_bands = false;                // option "coarse_bands": a coarse layer whose per-pair working set exceeds band_mb is swept like the finest one
                                               // (measured at 3840x2160 / 5 layers: 584 vs 594 pairs/s -- half-size launches cost more than the cache returns; off)
     int small_g = 0;                          // pairs the Ic / Rc buffers were sized for (0: none)
@@ -947,12 +947,15 @@ static SweepPlan plan_sweeps(const mav_ctx* c, int k, int g, bool bands_ok)
 // above have written into Ma (their odd sweeps end one whole tile row higher); the rows two neighbouring bands both need are
 // simply built twice, to the same values.
 struct BandUpdate { const float* flow_prev; size_t fc_stride; int pw, ph; float mul; };
-// phase = 1 (the pairs of the second stream, option "band_phase"): the partition is shifted by half a band -- J + 1 bands, the first and
-// the last of half size.  Two streams that start a group together with the same partition stay in lockstep: both build a band's initial M
-// (HBM-bound) at the same moments and both sweep (cache-bound) at the same moments -- measured untraced at 3840x2160: 1.3 ms per step with
-// two initial-M launches running and no sweep, 1.0 ms with one.  Half a band out of phase, one stream's initial M falls into the other's
-// sweeps.  The band arguments above hold for any monotone sequence of boundaries (a band whose rows have all moved above the image top
-// at a late sweep is empty and skipped; its successor then starts at row 0).
+// phase = 1 (the pairs of the second stream, option "band_phase", off by default): the partition is shifted by half a band -- J + 1 bands,
+// the first and the last of half size.  Two streams that start a group together with the same partition stay in lockstep: both build a
+// band's initial M (HBM-bound) at the same moments and both sweep (cache-bound) at the same moments -- untraced at 3840x2160: 1.3 ms per
+// step with two initial-M launches running and no sweep, 1.0 ms with one (tools/untraced_anatomy.py).  Shifted by half a band, one
+// stream's initial M does fall into the other's sweeps (3.6 ms per step) -- and the step gets SLOWER: 581 vs 602 pairs/s at 4K, 2 320 vs
+// 2 630 at 1080p (profiles/r04/ab_band_phase.log): the 66 MB a band's initial M streams in from HBM push the sweeping pair's band out
+// of the Infinity Cache (sweep launches 37.1 vs 34.6 ms summed).  The lockstep is worth keeping.  The band arguments above hold for any
+// monotone sequence of boundaries (a band whose rows have all moved above the image top at a late sweep is empty and skipped; its
+// successor then starts at row 0): bit-identical (tests/test_gpu_flow.py).
 static void sweeps_band_major(mav_ctx* c, hipStream_t st, int kid, float* Ma, float* Mb, size_t ms, const float* r0, const float* r1, size_t rs, int gs,
                               int lw, int lh, int T, int J, float* fo, size_t fstride, const BandUpdate* upd = nullptr, bool two_streams = false,
                               int phase = 0)

@@ -354,7 +354,7 @@ def test_options_are_reported_and_validated(mav):
         assert info["layers"][1]["blur"] == "fused" and info["layers"][1]["pairs_per_launch"] == 4
         for name, v in (("band_mb", 40), ("coarse_half", 3), ("strip", 20), ("phi_yloop", 4), ("phi_screen", 0), ("share_m", 0),
                         ("coarse_cache_mb", 100), ("bands", 3), ("group_fine", 2), ("small_batch", 0), ("sweep_write_through", 1),
-                        ("deep_batch", 0), ("coarse_bands", 1), ("band_phase", 0)):
+                        ("deep_batch", 0), ("coarse_bands", 1), ("band_phase", 2)):
             c.set_option(name, v)
             assert c.get_option(name) == v
             assert c.schedule_info(64)[name] == v
