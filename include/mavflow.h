@@ -84,7 +84,7 @@ int mav_device_count(void);       /* <= 0 when no GPU is visible */
  *   "group_fine"       pairs per launch for the finest layer's sweeps (default 1: one pair's working set stays in the Infinity Cache;
  *                      0 = same as group)
  *   "pairs_in_flight"  1 | 2 (default 2): the finest layer's per-pair work of a group alternates between two streams, every pair swept
- *                      band by band (bands of <= "band_mb" MB of working set, default 86, or "bands" when set) so that both stay in
+ *                      band by band (bands of <= "band_mb" MB of working set, default 96, or "bands" when set) so that both stay in
  *                      the Infinity Cache; the coarse layers alternate sub-groups of "coarse_half" pairs (0 = half the count that fits
  *                      "coarse_cache_mb", default 220) between the two streams
  *   "bands"            J in [1, 8]: a pair's finest-layer sweeps run band by band over J skewed horizontal bands; 0 = automatic (the

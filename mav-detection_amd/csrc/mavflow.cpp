@@ -242,7 +242,9 @@ struct mav_ctx {
     int bands = 1;                   // option "bands": the finest layer's sweeps in band-major order over this many skewed bands
     // option "pairs_in_flight" (1 or 2): the finest layer's per-pair work (initial M + sweeps) of a group alternates between the
     // compute stream and pair_stream, every pair band-major over bands of at most pif_band_mb of working set (layer_sweeps)
-    int pairs_in_flight = 2, pif_band_mb = 86;
+    // band_mb 96: 2 bands at 1080p (83 MB each), 7 at 3840x2160 (95 MB, ~1 160 tiles per launch on 1 280 resident slots): 608 vs 605
+    // pairs/s with 8 bands of 83 MB, 597 with 6 of 111 MB, 567 with 5 (profiles/r04/ab_band_mb_4k.log)
+    int pairs_in_flight = 2, pif_band_mb = 96;
     bool bands_set = false;          // "bands" given explicitly: that many bands in either schedule
     int bands_auto = 1;              // what "bands" = 0 restores
     bool group_fine_set = false;     // "group_fine" given explicitly

@@ -360,7 +360,7 @@ def test_options_are_reported_and_validated(mav):
             assert c.schedule_info(64)[name] == v
         c.set_option("bands", 0)                                     # back to automatic
         c.set_option("group_fine", 1)
-        c.set_option("band_mb", 86)
+        c.set_option("band_mb", 96)
         assert c.schedule_info(64)["layers"][0]["bands"] == 2
         for name, v in (("pairs_in_flight", 3), ("bands", 9), ("group", 0), ("no_such_option", 1), ("recompute", 1), ("pipeline", 1)):
             with pytest.raises(ValueError):
@@ -455,7 +455,7 @@ def test_two_pairs_in_flight_give_the_same_flow(mav, size, batch, group):
 
 
 @pytest.mark.parametrize("size,levels,batch,group,band_mb", [((1920, 1080), 3, 5, 2, 8), ((1000, 562), 4, 7, 3, 8), ((640, 480), 2, 6, 2, 8),
-                                                             ((3840, 2160), 5, 3, 2, 86)])
+                                                             ((3840, 2160), 5, 3, 2, 96)])
 def test_deep_layers_once_per_call_and_banded_coarse_layers_are_bit_identical(mav, size, levels, batch, group, band_mb):
     """Round 4's two schedule changes for many-layer pyramids (BASELINE config 5: 3840x2160, five layers).
     "deep_batch": the layers at the top of the pyramid (each at most 1/32 of the frame) run ONCE for all pairs of a call -- their images
