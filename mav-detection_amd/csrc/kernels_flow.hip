@@ -561,25 +561,71 @@ static __device__ __forceinline__ void blur_fused_tile(const uint8_t* __restrict
 //     loads in flight; every staged row lies inside the image (ylo + row <= yhi <= H - 1), so no clamping;
 //   * the H pass does not clamp its row index: rows past n_rows (at most 3, LDS the launch allocates) are computed and not stored;
 //   * interior tiles (every row's taps inside the image) take a V pass without the reflect-101 tests.
+// The (b0, b1)-pair form of blur_h4_pairs for a Gaussian whose length is a template argument (the fused tile: 5 and 13 taps): the
+// KS + 1 tap pairs (g[t], g[t - 1]) are wave-uniform values the caller builds once per thread (TapPairs), byte t of a row costs one
+// conversion and one packed FMA.  Same accumulation order as blur_h4_stream: same bits.
+template <int KS> struct TapPairs {
+    mav_f2 G[KS + 1];
+    __device__ __forceinline__ void load(const BlurParams& bp)
+    {
+#pragma unroll
+        for (int t = 0; t <= KS; t++) { G[t].x = t < KS ? bp.g[t] : 0.f; G[t].y = t >= 1 ? bp.g[t - 1] : 0.f; }
+    }
+};
+template <int KS, typename WordFn>
+static __device__ __forceinline__ void blur_h4_pairs_t(WordFn rd, int off, float f, const TapPairs<KS>& tp, float out[4])
+{
+    const int w0 = off >> 2;
+    const unsigned sh = (unsigned)(off & 3);
+    constexpr int NW = (KS + 1 + 3) / 4;
+    mav_f2 acc[4];
+    uint32_t lo[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { acc[k] = (mav_f2)(0.f, 0.f); lo[k] = rd(k, w0); }
+#pragma unroll
+    for (int c = 0; c < NW; c++) {
+        uint32_t cur[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t hi = rd(k, w0 + c + 1);
+            cur[k] = __builtin_amdgcn_alignbyte(hi, lo[k], sh);
+            lo[k] = hi;
+        }
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            if (4 * c + b > KS) break;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float p = (float)((cur[k] >> (8 * b)) & 0xffu);
+                acc[k] = __builtin_elementwise_fma(tp.G[4 * c + b], (mav_f2)(p, p), acc[k]);
+            }
+        }
+    }
+    const float a0 = 1.f - f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[k] = fmaf(acc[k].y, f, acc[k].x * a0);
+}
 template <int KS>
-static __device__ __forceinline__ float blur_v1_interior(const float* __restrict__ col, int s0, float f, const BlurParams& bp)
+static __device__ __forceinline__ float blur_v1_interior(const float* __restrict__ col, int s0, float f, const TapPairs<KS>& tp)
 {
     constexpr int r = KS >> 1;
     float px[KS + 1];
 #pragma unroll
     for (int t = 0; t <= KS; t++) px[t] = col[(s0 - r + t) * 64];
-    float b0 = 0.f, b1 = 0.f;
+    mav_f2 acc = (mav_f2)(0.f, 0.f);                                         // (b0, b1): row t feeds b0 with g[t] and b1 with g[t - 1]
 #pragma unroll
-    for (int t = 0; t < KS; t++) { const float g = bp.g[t]; b0 = fmaf(g, px[t], b0); b1 = fmaf(g, px[t + 1], b1); }
-    return fmaf(b1, f, b0 * (1.f - f));
+    for (int t = 0; t <= KS; t++) acc = __builtin_elementwise_fma(tp.G[t], (mav_f2)(px[t], px[t]), acc);
+    return fmaf(acc.y, f, acc.x * (1.f - f));
 }
 template <int KS, int TH>
 static __device__ __forceinline__ void blur_fused_tile_fast(const uint8_t* __restrict__ base, float* __restrict__ out, int W, int H, int w, int h,
                                                             const BlurParams& bp, int rows_cap, int pitch_w, int tile_x, int tile_y,
                                                             float* __restrict__ hrows)
 {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (wave-uniform: scalar row bookkeeping)
     constexpr int r = KS >> 1;
+    TapPairs<KS> tp;
+    tp.load(bp);
     const int dx = tile_x * 64 + lane, dxc = min(dx, w - 1);
     const int dy0 = tile_y * TH, dy1 = min(dy0 + TH, h) - 1;
     const int dyc = min(dy0 + (lane & (TH - 1)), h - 1);
@@ -636,7 +682,7 @@ static __device__ __forceinline__ void blur_fused_tile_fast(const uint8_t* __res
     for (int i = wv * 4; i < n_rows; i += 16) {
         float o[4];
         const uint32_t* rw = sw + i * pitch_w;
-        blur_h4_stream_t<KS>([&](int k, int wi) { return rw[k * pitch_w + wi]; }, off, f, bp, o);
+        blur_h4_pairs_t<KS>([&](int k, int wi) { return rw[k * pitch_w + wi]; }, off, f, tp, o);
 #pragma unroll
         for (int k = 0; k < 4; k++)
             if (i + k < n_rows) hrows[(i + k) * 64 + lane] = o[k];
@@ -651,7 +697,7 @@ static __device__ __forceinline__ void blur_fused_tile_fast(const uint8_t* __res
         if (dy > dy1) break;
         const int t0 = __builtin_amdgcn_readlane(row_s, j * 4 + wv);
         const float tf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(row_f), j * 4 + wv));
-        const float v = interior ? blur_v1_interior<KS>(col, t0, tf, bp) : blur_v1([&](int y) { return col[y * 64]; }, H, t0, tf, bp);
+        const float v = interior ? blur_v1_interior<KS>(col, t0, tf, tp) : blur_v1([&](int y) { return col[y * 64]; }, H, t0, tf, bp);
         if (dx < w) out[(size_t)dy * w + dx] = v;
     }
 }
