@@ -165,12 +165,15 @@ def equal_plain_schedule(ctx, run_batch, d_res, d_mf, d_md, B, W, H):
         return (d_res.download(np.uint8, (B * rec,)).tobytes(), zlib.crc32(d_mf.download(np.uint8, (B * W * H,))),
                 zlib.crc32(d_md.download(np.uint8, (B * W * H,))), [zlib.crc32(ctx.last_flow(b)) for b in range(B)])
     timed = digest()
-    saved = ctx.get_option("pairs_in_flight")
-    ctx.set_option("pairs_in_flight", 1)
+    plain_opts = {"pairs_in_flight": 1, "deep_batch": 0, "coarse_bands": 0, "band_phase": 0}     # one stream, every layer per group
+    saved = {k: ctx.get_option(k) for k in plain_opts}
+    for k, v in plain_opts.items():
+        ctx.set_option(k, v)
     run_batch()
     ctx.sync()
     plain = digest()
-    ctx.set_option("pairs_in_flight", saved)
+    for k, v in saved.items():
+        ctx.set_option(k, v)
     same = [b for b in range(B) if timed[3][b] == plain[3][b]]
     ok = bool(timed[:3] == plain[:3] and len(same) == B)
     differing = sorted(set(range(B)) - set(same)) if not ok else []

@@ -606,26 +606,33 @@ static __device__ __forceinline__ void blur_h4_pairs_t(WordFn rd, int off, float
     for (int k = 0; k < 4; k++) out[k] = fmaf(acc[k].y, f, acc[k].x * a0);
 }
 template <int KS>
-static __device__ __forceinline__ float blur_v1_interior(const float* __restrict__ col, int s0, float f, const TapPairs<KS>& tp)
+static __device__ __forceinline__ float blur_v1_interior(const float* __restrict__ col, int s0, float f, const TapPairs<KS>& tp, const BlurParams& bp)
 {
     constexpr int r = KS >> 1;
     float px[KS + 1];
 #pragma unroll
     for (int t = 0; t <= KS; t++) px[t] = col[(s0 - r + t) * 64];
-    mav_f2 acc = (mav_f2)(0.f, 0.f);                                         // (b0, b1): row t feeds b0 with g[t] and b1 with g[t - 1]
+    if constexpr (KS >= 13) {
+        mav_f2 acc = (mav_f2)(0.f, 0.f);                                     // (b0, b1): row t feeds b0 with g[t] and b1 with g[t - 1]
 #pragma unroll
-    for (int t = 0; t <= KS; t++) acc = __builtin_elementwise_fma(tp.G[t], (mav_f2)(px[t], px[t]), acc);
-    return fmaf(acc.y, f, acc.x * (1.f - f));
+        for (int t = 0; t <= KS; t++) acc = __builtin_elementwise_fma(tp.G[t], (mav_f2)(px[t], px[t]), acc);
+        return fmaf(acc.y, f, acc.x * (1.f - f));
+    } else {
+        float b0 = 0.f, b1 = 0.f;
+#pragma unroll
+        for (int t = 0; t < KS; t++) { const float g = bp.g[t]; b0 = fmaf(g, px[t], b0); b1 = fmaf(g, px[t + 1], b1); }
+        return fmaf(b1, f, b0 * (1.f - f));
+    }
 }
 template <int KS, int TH>
 static __device__ __forceinline__ void blur_fused_tile_fast(const uint8_t* __restrict__ base, float* __restrict__ out, int W, int H, int w, int h,
                                                             const BlurParams& bp, int rows_cap, int pitch_w, int tile_x, int tile_y,
                                                             float* __restrict__ hrows)
 {
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (wave-uniform: scalar row bookkeeping)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     constexpr int r = KS >> 1;
     TapPairs<KS> tp;
-    tp.load(bp);
+    if constexpr (KS >= 13) tp.load(bp);                                   // (the pair form: 13 taps only, see below)
     const int dx = tile_x * 64 + lane, dxc = min(dx, w - 1);
     const int dy0 = tile_y * TH, dy1 = min(dy0 + TH, h) - 1;
     const int dyc = min(dy0 + (lane & (TH - 1)), h - 1);
@@ -682,7 +689,10 @@ static __device__ __forceinline__ void blur_fused_tile_fast(const uint8_t* __res
     for (int i = wv * 4; i < n_rows; i += 16) {
         float o[4];
         const uint32_t* rw = sw + i * pitch_w;
-        blur_h4_pairs_t<KS>([&](int k, int wi) { return rw[k * pitch_w + wi]; }, off, f, tp, o);
+        // (the pair form pays for 13 taps -- 184 vs 194 us per launch for layer 2 of the 4K preset -- and costs for 5: 64 vs 53 us per
+        // launch for layer 1 at 1080p, where the compiler's own mix of scalar-tap FMAs is shorter)
+        if constexpr (KS >= 13) blur_h4_pairs_t<KS>([&](int k, int wi) { return rw[k * pitch_w + wi]; }, off, f, tp, o);
+        else blur_h4_stream_t<KS>([&](int k, int wi) { return rw[k * pitch_w + wi]; }, off, f, bp, o);
 #pragma unroll
         for (int k = 0; k < 4; k++)
             if (i + k < n_rows) hrows[(i + k) * 64 + lane] = o[k];
@@ -697,7 +707,7 @@ static __device__ __forceinline__ void blur_fused_tile_fast(const uint8_t* __res
         if (dy > dy1) break;
         const int t0 = __builtin_amdgcn_readlane(row_s, j * 4 + wv);
         const float tf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(row_f), j * 4 + wv));
-        const float v = interior ? blur_v1_interior<KS>(col, t0, tf, tp) : blur_v1([&](int y) { return col[y * 64]; }, H, t0, tf, bp);
+        const float v = interior ? blur_v1_interior<KS>(col, t0, tf, tp, bp) : blur_v1([&](int y) { return col[y * 64]; }, H, t0, tf, bp);
         if (dx < w) out[(size_t)dy * w + dx] = v;
     }
 }
@@ -706,29 +716,42 @@ static __host__ __device__ __forceinline__ bool fused_fast_ok(const BlurParams& 
 {
     return dword_ok && pitch_w > 0 && bp.xs != nullptr && (bp.ksize == 5 || bp.ksize == 13);
 }
+// Which tile code a fused launch carries.  One kernel per PATH: the paths differ a lot in registers (the generic tile and the 13-tap
+// pair form want ~80 VGPRs, the 5-tap fast tile 44), and a kernel that contained them all ran the 5-tap layers at the occupancy of
+// the hungriest (66 vs 53 us per launch for layer 1 at 1080p).
+enum { FP_GENERIC = 0, FP_FAST5 = 1, FP_FAST13 = 2, FP_ANY = 3 };
+static int fused_path_of(const BlurParams& bp, int pitch_w, int dword_ok)
+{
+    return !fused_fast_ok(bp, pitch_w, dword_ok) ? FP_GENERIC : (bp.ksize == 5 ? FP_FAST5 : FP_FAST13);
+}
+template <int PATH>
 static __device__ __forceinline__ void blur_fused_any(const uint8_t* __restrict__ base, float* __restrict__ out, int W, int H, int w, int h,
                                                       const BlurParams& bp, int rows_cap, int pitch_w, int dword_ok, int th, int tile_x, int tile_y,
                                                       float* __restrict__ hrows)
 {
     // th = tile height chosen by the host (fused_plan): 16, or 8 where 16 rows' source region does not fit LDS (fast tile only)
-    if (fused_fast_ok(bp, pitch_w, dword_ok)) {
-        if (bp.ksize == 5) {
-            if (th == 16) blur_fused_tile_fast<5, 16>(base, out, W, H, w, h, bp, rows_cap, pitch_w, tile_x, tile_y, hrows);
-            else blur_fused_tile_fast<5, 8>(base, out, W, H, w, h, bp, rows_cap, pitch_w, tile_x, tile_y, hrows);
-        } else {
-            if (th == 16) blur_fused_tile_fast<13, 16>(base, out, W, H, w, h, bp, rows_cap, pitch_w, tile_x, tile_y, hrows);
-            else blur_fused_tile_fast<13, 8>(base, out, W, H, w, h, bp, rows_cap, pitch_w, tile_x, tile_y, hrows);
-        }
-    } else
+    const bool fast = PATH == FP_FAST5 || PATH == FP_FAST13 || (PATH == FP_ANY && fused_fast_ok(bp, pitch_w, dword_ok));
+    if ((PATH == FP_FAST5 || PATH == FP_ANY) && fast && bp.ksize == 5) {
+        if (th == 16) blur_fused_tile_fast<5, 16>(base, out, W, H, w, h, bp, rows_cap, pitch_w, tile_x, tile_y, hrows);
+        else blur_fused_tile_fast<5, 8>(base, out, W, H, w, h, bp, rows_cap, pitch_w, tile_x, tile_y, hrows);
+        return;
+    }
+    if ((PATH == FP_FAST13 || PATH == FP_ANY) && fast && bp.ksize == 13) {
+        if (th == 16) blur_fused_tile_fast<13, 16>(base, out, W, H, w, h, bp, rows_cap, pitch_w, tile_x, tile_y, hrows);
+        else blur_fused_tile_fast<13, 8>(base, out, W, H, w, h, bp, rows_cap, pitch_w, tile_x, tile_y, hrows);
+        return;
+    }
+    if (PATH == FP_GENERIC || PATH == FP_ANY)
         blur_fused_tile(base, out, W, H, w, h, bp, rows_cap, pitch_w, dword_ok, tile_x, tile_y, hrows);
 }
+template <int PATH>
 __global__ __launch_bounds__(256) void k_blur_resize_fused(const uint8_t* __restrict__ img, const uint8_t* __restrict__ img2, int split,
                                                            size_t img_stride, int W, int H, int w, int h, BlurParams bp,
                                                            float* __restrict__ out, size_t out_stride, int rows_cap, int pitch_w, int dword_ok, int th)
 {
     extern __shared__ __attribute__((aligned(16))) float hrows[];       // [rows_cap][64] f32, then [rows_cap + 3][pitch_w] dwords of u8
-    blur_fused_any(image_of(img, img2, split, img_stride, blockIdx.z), out + (size_t)blockIdx.z * out_stride, W, H, w, h, bp, rows_cap, pitch_w,
-                   dword_ok, th, blockIdx.x, blockIdx.y, hrows);
+    blur_fused_any<PATH>(image_of(img, img2, split, img_stride, blockIdx.z), out + (size_t)blockIdx.z * out_stride, W, H, w, h, bp, rows_cap,
+                         pitch_w, dword_ok, th, blockIdx.x, blockIdx.y, hrows);
 }
 
 static int fused_blur_rows(int H, int h, int ksize, int th = FB_TH) { return (int)((th - 1) * ((double)H / h)) + (ksize | 1) + 4; }
@@ -807,6 +830,7 @@ static __device__ __forceinline__ void blur3_block(const uint8_t* __restrict__ s
 
 // The layer images of SEVERAL layers in one launch (a small group's pyramid: launch_blur_multi): job 0.. = layers whose blur is the
 // 3x3 form (layer 0) or the fused form; workgroup b belongs to the last job whose first_block is <= b.
+template <int PATH>      // the tile code its fused jobs need (FP_ANY when they differ)
 __global__ __launch_bounds__(256) void k_blur_multi(const uint8_t* __restrict__ img, const uint8_t* __restrict__ img2, int split, size_t img_stride,
                                                     int W, int H, int dword_ok, BlurJobs jobs)
 {
@@ -819,7 +843,7 @@ __global__ __launch_bounds__(256) void k_blur_multi(const uint8_t* __restrict__ 
     const int by = rem / J.gx, bx = rem - by * J.gx;
     const uint8_t* base = image_of(img, img2, split, img_stride, z);
     float* out = J.out + (size_t)z * J.out_stride;
-    if (J.fused) blur_fused_any(base, out, W, H, J.w, J.h, J.bp, J.rows_cap, J.pitch_w, dword_ok, J.th, bx, by, hrows);
+    if (J.fused) blur_fused_any<PATH>(base, out, W, H, J.w, J.h, J.bp, J.rows_cap, J.pitch_w, dword_ok, J.th, bx, by, hrows);
     else blur3_block(base, out, W, H, bx, by);
 }
 // Layer images of several layers of G frames in ONE launch.  jobs[i]: layer size, BlurParams, out / out_stride filled by the caller; a
@@ -852,7 +876,18 @@ void launch_blur_multi(hipStream_t st, const uint8_t* img, const uint8_t* img2, 
         J.first_block = blocks;
         blocks += J.gx * J.gy * G;
     }
-    hipLaunchKernelGGL(k_blur_multi, dim3(blocks), dim3(256), lds, st, img, img2, split, img_stride, W, H, dword_ok, jobs);
+    int path = -1;                                                          // one tile code for all fused jobs, or FP_ANY
+    for (int i = 0; i < jobs.n; i++)
+        if (jobs.j[i].fused) {
+            const int p = fused_path_of(jobs.j[i].bp, jobs.j[i].pitch_w, dword_ok);
+            path = path < 0 ? p : (path == p ? p : FP_ANY);
+        }
+    switch (path) {
+    case FP_FAST13: hipLaunchKernelGGL(k_blur_multi<FP_FAST13>, dim3(blocks), dim3(256), lds, st, img, img2, split, img_stride, W, H, dword_ok, jobs); break;
+    case FP_GENERIC: hipLaunchKernelGGL(k_blur_multi<FP_GENERIC>, dim3(blocks), dim3(256), lds, st, img, img2, split, img_stride, W, H, dword_ok, jobs); break;
+    case FP_ANY: hipLaunchKernelGGL(k_blur_multi<FP_ANY>, dim3(blocks), dim3(256), lds, st, img, img2, split, img_stride, W, H, dword_ok, jobs); break;
+    default: hipLaunchKernelGGL(k_blur_multi<FP_FAST5>, dim3(blocks), dim3(256), lds, st, img, img2, split, img_stride, W, H, dword_ok, jobs); break;   // (also: no fused job)
+    }
 }
 
 // G images: the first `split` from run img, the rest from run img2 (both with stride img_stride); split >= G: one run.
@@ -889,8 +924,12 @@ void launch_blur_resize(hipStream_t st, const uint8_t* img, const uint8_t* img2,
     const int pitch_w = staged_pitch_words(W, w, bp.ksize);
     if (!two_pass && blur_resize_is_fused(W, H, w, h, bp.ksize)) {
         const FusedPlan fp = fused_plan(W, H, w, h, bp, dword_ok);
-        hipLaunchKernelGGL(k_blur_resize_fused, dim3((w + 63) / 64, (h + fp.th - 1) / fp.th, G), dim3(256), fp.lds, st, img,
-                           img2, split, img_stride, W, H, w, h, bp, out, out_stride, fp.rows, fp.pitch_w, dword_ok, fp.th);
+        const dim3 grid((w + 63) / 64, (h + fp.th - 1) / fp.th, G);
+        switch (fused_path_of(bp, fp.pitch_w, dword_ok)) {
+        case FP_FAST5: hipLaunchKernelGGL(k_blur_resize_fused<FP_FAST5>, grid, dim3(256), fp.lds, st, img, img2, split, img_stride, W, H, w, h, bp, out, out_stride, fp.rows, fp.pitch_w, dword_ok, fp.th); break;
+        case FP_FAST13: hipLaunchKernelGGL(k_blur_resize_fused<FP_FAST13>, grid, dim3(256), fp.lds, st, img, img2, split, img_stride, W, H, w, h, bp, out, out_stride, fp.rows, fp.pitch_w, dword_ok, fp.th); break;
+        default: hipLaunchKernelGGL(k_blur_resize_fused<FP_GENERIC>, grid, dim3(256), fp.lds, st, img, img2, split, img_stride, W, H, w, h, bp, out, out_stride, fp.rows, fp.pitch_w, dword_ok, fp.th); break;
+        }
         return;
     }
     int rows_blk = 16;
