@@ -11,8 +11,10 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/
 timeout -k 10 120 rocprofv3 --kernel-trace --output-format csv -d "$out/ktc2" -- python3 tools/c2_probe.py 1280 720 1 50 > "$out/ktc2.log" 2>&1 || exit 1
 tools/pmc_passes.sh "$out/pmc1080" --batch 64 > "$out/pmc1080.log" 2>&1 || exit 1
 tools/pmc_passes.sh "$out/pmc4k" $B4K > "$out/pmc4k.log" 2>&1 || exit 1
+tools/pmc_passes.sh "$out/pmc720" --width 1280 --height 720 --batch 1 > "$out/pmc720.log" 2>&1 || exit 1
 python3 tools/make_traffic.py "$out/pmc1080" "$out/traffic.json" --batch 64 > /dev/null || exit 1
 python3 tools/make_traffic.py "$out/pmc4k" "$out/traffic_4k.json" --width 3840 --height 2160 --levels 5 --batch 16 > /dev/null || exit 1
+python3 tools/make_traffic.py "$out/pmc720" "$out/traffic_720p.json" --width 1280 --height 720 --levels 1 --batch 1 > /dev/null || exit 1
 # sweep launches overlap (two pairs in flight): busy time = union of the dispatch intervals of the kernel trace
 for t in kt1080 kt4k; do
   per=$(python3 -c "import json,sys; print(json.loads(open('$out/$t.json').readline())['roofline']['alg_bytes_per_launch_avg'])")
@@ -20,4 +22,9 @@ for t in kt1080 kt4k; do
   python3 tools/step_anatomy.py "$out"/$t/runc/*_kernel_trace.csv 3 > "$out/step_anatomy_$t.txt" || exit 1
 done
 python3 tools/trace_timeline.py "$out"/ktc2/runc/*_kernel_trace.csv --last 27 > "$out/c2_timeline.txt" || exit 1
+# the same anatomy WITHOUT a tracer (HIP events around runs of launches / around every launch) and the layer-image kernels per launch
+python3 tools/untraced_anatomy.py 1920 1080 64 1 > "$out/untraced_anatomy_1080p_b64.txt" 2>&1 || exit 1
+python3 tools/untraced_anatomy.py 3840 2160 16 5 > "$out/untraced_anatomy_4k_l5_b16.txt" 2>&1 || exit 1
+python3 tools/blur_launches.py "$out"/kt1080/runc/*_kernel_trace.csv > "$out/layer_image_launches_1080p_b64.txt" || exit 1
+python3 tools/blur_launches.py "$out"/kt4k/runc/*_kernel_trace.csv > "$out/layer_image_launches_4k_l5_b16.txt" || exit 1
 find "$out" -name "*kernel_stats.csv" | head
