@@ -100,10 +100,6 @@ int mav_device_count(void);       /* <= 0 when no GPU is visible */
  *                      up to 64 pairs of the call before the groups start, instead of once per group
  *   "coarse_bands"     default 0: 1 = a coarse layer whose per-pair working set exceeds "band_mb" (layer 1 of the 4K preset, 106 MB) is
  *                      swept like the finest layer, pairs alternating between the two streams band by band (measured slower: off)
- *   "prev_by_band"     default 1: in the two-stream, band-major schedule of the finest layer (independent pairs) the polynomial expansion of
- *                      a pair's PREV frame is built band by band right before the band's initial M, into a buffer of the pair's stream
- *                      that all its pairs re-use, instead of with the group's batched expansions: that expansion never makes the
- *                      round trip through HBM; 0 = every expansion batched per group
  *   "band_phase"       default 0; n > 0: in the two-stream schedule the pairs of the second stream use a band partition shifted by half a
  *                      band whenever a pair has at least n bands, so that the two streams do not build their bands' initial M (HBM-bound)
  *                      at the same moments (measured slower: the lockstep of the two streams protects the Infinity Cache)

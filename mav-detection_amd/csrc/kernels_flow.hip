@@ -1084,12 +1084,11 @@ void launch_polyexp_multi(hipStream_t st, PolyJobs jobs, int G, const PolyCoef& 
 }
 
 void launch_polyexp(hipStream_t st, const float* I, size_t I_stride, int G, int w, int h, const PolyCoef& pc, float* R,
-                    size_t R_stride, int ty0, int ty1)
+                    size_t R_stride)
 {
     const int n = pc.n;
     const size_t lds = sizeof(float) * ((size_t)(PX + 2 * n) * (PY + 2 * n) + 3 * (size_t)PY * (PX + 2 * n));
-    TileMap tm = make_tile_map(w, h, G, PX, PY, ty0, ty1);
-    if (tm.n_tiles == 0) return;
+    TileMap tm = make_tile_map(w, h, G, PX, PY);
     tm.xcd = 0;        // plain row-major order: measured 3 % faster here than the XCD-banded order (the halo re-reads that miss
                        // L2 hit the Infinity Cache, which all XCDs share; the kernel is VALU / write bound, not read bound)
     const dim3 grid(tile_grid(tm));

@@ -231,13 +231,6 @@ struct mav_ctx {
     struct DeepSet { float *I = nullptr, *R = nullptr, *Ma = nullptr, *Mb = nullptr, *f[2] = {nullptr, nullptr}; } deep;
     int kd = 0, deep_cap = 0;                 // kd = 0: no deep layer
     bool deep_batch = true;                   // option "deep_batch"
-    // option "prev_by_band" (two-stream, band-major schedule of the finest layer, independent pairs): the expansion of a pair's PREV
-    // frame is not part of the group's batched expansions; it is built band by band, right before the band's initial M, into a frame-sized
-    // buffer of the pair's stream (R0s[stream]) that every pair of that stream re-uses -- the band's R0 then never makes the round trip
-    // through HBM (20 B/px written by the batched expansion + 20 B/px read back by the initial M), and the arithmetic-bound expansion
-    // runs beside the other stream's memory-bound launches.  Same tile function on the same layer image: same bits.
-    float* R0s[2] = {nullptr, nullptr};
-    int prev_by_band = 1;
     int band_phase = 0;                       // option "band_phase": n > 0 = the second stream's pairs use a partition shifted by half a band
                                               // when a pair has at least n bands (sweeps_band_major); 0 = never (default: measured slower)
     bool coarse_bands = false;                // option "coarse_bands": a coarse layer whose per-pair working set exceeds band_mb is swept like the finest one
@@ -390,19 +383,6 @@ static int alloc_group(mav_ctx* c, int group)
         }
         c->deep.I = d[0]; c->deep.R = d[1]; c->deep.Ma = d[2]; c->deep.Mb = d[3]; c->deep.f[0] = d[4]; c->deep.f[1] = d[5];
     }
-    if (!c->R0s[0]) {                                   // the per-stream R0 buffers of "prev_by_band" (independent of the group)
-        for (int i = 0; i < 2; i++) {
-            const hipError_t e = hipMalloc(&c->R0s[i], sizeof(float) * 5 * c->n0);
-            if (e != hipSuccess) {
-                if (c->R0s[0]) hipFree(c->R0s[0]);
-                c->R0s[0] = c->R0s[1] = nullptr;
-                for (int j = 0; j < NB; j++) if (fresh[j]) hipFree(fresh[j]);
-                (void)hipGetLastError();
-                return fail(e == hipErrorOutOfMemory ? MAV_ERR_OOM : MAV_ERR_HIP, "per-stream expansion buffers (%zu bytes): %s", sizeof(float) * 5 * c->n0, hipGetErrorString(e));
-            }
-            c->deep_bytes += sizeof(float) * 5 * c->n0;
-        }
-    }
     mav_ctx::WorkSet& w = c->ws;
     float** bufs[NB] = {&w.I, &w.R, &w.Ma, &w.Mb, &w.fc[0], &w.fc[1], &w.Htmp, &w.Ic, &w.Rc};
     for (int i = 0; i < NB; i++) { if (*bufs[i]) hipFree(*bufs[i]); *bufs[i] = fresh[i]; }
@@ -435,7 +415,7 @@ extern "C" int mav_destroy(mav_ctx* c)
     for (auto& l : c->layers) free_layer(l);
     {
         mav_ctx::WorkSet& w = c->ws;
-        void* wb[] = {w.I, w.R, w.Ma, w.Mb, w.fc[0], w.fc[1], w.Htmp, w.Ic, w.Rc, c->deep.I, c->deep.R, c->deep.Ma, c->deep.Mb, c->deep.f[0], c->deep.f[1], c->R0s[0], c->R0s[1]};
+        void* wb[] = {w.I, w.R, w.Ma, w.Mb, w.fc[0], w.fc[1], w.Htmp, w.Ic, w.Rc, c->deep.I, c->deep.R, c->deep.Ma, c->deep.Mb, c->deep.f[0], c->deep.f[1]};
         for (void* b : wb) if (b) hipFree(b);
     }
     void* bufs[] = {c->flow_ws, c->foe_sc.cand, c->foe_sc.count, c->foe_sc.best_key, c->foe_sc.done, c->foe_dev, c->box_acc, c->u64_scratch,
@@ -570,7 +550,7 @@ static const OptionDesc kOptions[] = {
     {"group", 1, 1 << 20}, {"group_fine", 0, 1 << 20}, {"bands", 0, 8}, {"pairs_in_flight", 1, 2}, {"band_mb", 8, 1 << 20},
     {"coarse_cache_mb", 0, 1 << 20}, {"coarse_half", 0, 1 << 20}, {"share_m", 0, 1}, {"share_frames", 0, 1}, {"strip", 0, 1 << 20},
     {"phi_screen", 0, 1}, {"phi_yloop", 0, 1 << 20}, {"small_batch", 0, 1}, {"sweep_write_through", -1, 1}, {"deep_batch", 0, 1},
-    {"coarse_bands", 0, 1}, {"band_phase", 0, 64}, {"prev_by_band", 0, 1},
+    {"coarse_bands", 0, 1}, {"band_phase", 0, 64},
 };
 static long* option_slot(mav_ctx* c, const char* name, long* tmp)
 {
@@ -579,7 +559,7 @@ static long* option_slot(mav_ctx* c, const char* name, long* tmp)
         {"group", c->group}, {"group_fine", c->group_fine}, {"bands", c->bands}, {"pairs_in_flight", c->pairs_in_flight},
         {"band_mb", c->pif_band_mb}, {"coarse_cache_mb", c->coarse_cache_mb}, {"coarse_half", c->coarse_half}, {"share_m", c->share_m},
         {"share_frames", c->share_frames}, {"strip", c->strip}, {"phi_screen", c->phi_screen}, {"phi_yloop", c->phi_yloop},
-        {"small_batch", c->small_batch}, {"sweep_write_through", c->sweep_wt}, {"deep_batch", c->deep_batch}, {"coarse_bands", c->coarse_bands}, {"band_phase", c->band_phase}, {"prev_by_band", c->prev_by_band},
+        {"small_batch", c->small_batch}, {"sweep_write_through", c->sweep_wt}, {"deep_batch", c->deep_batch}, {"coarse_bands", c->coarse_bands}, {"band_phase", c->band_phase},
     };
     for (auto& e : cur) if (!strcmp(e.n, name)) { *tmp = e.v; return tmp; }
     return nullptr;
@@ -627,7 +607,6 @@ extern "C" int mav_set_option(mav_ctx* c, const char* name, long value)
     else if (!strcmp(name, "deep_batch")) c->deep_batch = v != 0;
     else if (!strcmp(name, "coarse_bands")) c->coarse_bands = v != 0;
     else if (!strcmp(name, "band_phase")) c->band_phase = v;
-    else if (!strcmp(name, "prev_by_band")) c->prev_by_band = v;
     return MAV_OK;
 }
 
@@ -969,8 +948,7 @@ static SweepPlan plan_sweeps(const mav_ctx* c, int k, int g, bool bands_ok)
 // first sweep: pixel rows [16 a0 - 8, 16 a1 + 8) -- what that sweep reads (6-pixel halo) -- which lie below everything the bands
 // above have written into Ma (their odd sweeps end one whole tile row higher); the rows two neighbouring bands both need are
 // simply built twice, to the same values.
-struct BandUpdate { const float* flow_prev; size_t fc_stride; int pw, ph; float mul;
-                    const float* I_prev; float* r0_build; };   // I_prev != nullptr: the band's R0 rows are expanded from this layer image into r0_build first
+struct BandUpdate { const float* flow_prev; size_t fc_stride; int pw, ph; float mul; };
 // phase = 1 (the pairs of the second stream, option "band_phase", off by default): the partition is shifted by half a band -- J + 1 bands,
 // the first and the last of half size.  Two streams that start a group together with the same partition stay in lockstep: both build a
 // band's initial M (HBM-bound) at the same moments and both sweep (cache-bound) at the same moments -- untraced at 3840x2160: 1.3 ms per
@@ -996,10 +974,6 @@ static void sweeps_band_major(mav_ctx* c, hipStream_t st, int kid, float* Ma, fl
     for (int j = 0; j < J; j++) {
         const int a0 = bound(j), a1 = bound(j + 1);
         if (a1 <= a0) continue;
-        if (upd && upd->I_prev) {      // tile rows the band's initial M and its sweeps read that no earlier band has built: up to a1 inclusive
-            ProfScope ps(c, K_POLYEXP, st);
-            launch_polyexp(st, upd->I_prev, 0, 1, lw, lh, c->pc, upd->r0_build, 0, a0 == 0 ? 0 : a0 + 1, j == J - 1 ? T : a1 + 1);
-        }
         if (upd) {
             ProfScope ps(c, K_UPDATE, st);
             launch_update_matrices(st, r0, r1, rs, upd->flow_prev, upd->fc_stride, upd->pw, upd->ph, upd->mul, gs, lw, lh, Ma, ms,
@@ -1034,14 +1008,12 @@ static void sweeps_plain(mav_ctx* c, hipStream_t ss, int kid, float* Min, float*
 // stream st.  flow_prev = the coarser layer's flow (pw x ph, slot stride fc_stride; nullptr at the top layer); the layer's flow goes to
 // fdst (slot stride fstride).  M ping-pongs through Ma / Mb (slot stride ms).  On return everything has been joined back into st.
 static int layer_sweeps(mav_ctx* c, hipStream_t st, int k, int g, const float* r0g, const float* r1g, size_t rs, const float* flow_prev,
-                        size_t fc_stride, int pw, int ph, float* fdst, size_t fstride, float* Ma, float* Mb, size_t ms,
-                        const float* I_prev = nullptr /* "prev_by_band": the prev frames' layer images (slot stride n0); r0g is then unused */)
+                        size_t fc_stride, int pw, int ph, float* fdst, size_t fstride, float* Ma, float* Mb, size_t ms)
 {
     const Layer& l = c->layers[k];
     const float mul = (float)(1. / c->fb.pyr_scale);
-    const bool bands_ok = blur_iter_bands_ok(l.w, c->fb.winsize, ms, rs, fstride, Ma, Mb, I_prev ? c->R0s[0] : r0g, r1g, fdst);
+    const bool bands_ok = blur_iter_bands_ok(l.w, c->fb.winsize, ms, rs, fstride, Ma, Mb, r0g, r1g, fdst);
     const SweepPlan p = plan_sweeps(c, k, g, bands_ok);
-    if (I_prev && !(p.mode == SW_TWO_PAIRS && p.J > 1)) return fail(MAV_ERR_STATE, "prev_by_band without a banded two-stream plan (layer %d)", k);
     const int kid = k == 0 ? K_ITER : K_ITER_COARSE;
     const int T = blur_iter_tile_rows(l.h);
     if (p.mode == SW_TWO_PAIRS) {
@@ -1050,10 +1022,9 @@ static int layer_sweeps(mav_ctx* c, hipStream_t st, int k, int g, const float* r
         for (int s0 = 0; s0 < g; s0++) {
             const hipStream_t ss = (s0 & 1) ? c->pair_stream : st;
             float *Min = Ma + (size_t)(s0 & 1) * ms, *Mout = Mb + (size_t)(s0 & 1) * ms;
-            const float *r0 = I_prev ? c->R0s[s0 & 1] : r0g + (size_t)s0 * rs, *r1 = r1g + (size_t)s0 * rs;
+            const float *r0 = r0g + (size_t)s0 * rs, *r1 = r1g + (size_t)s0 * rs;
             float* fo = fdst + (size_t)s0 * fstride;
-            const BandUpdate bu{flow_prev ? flow_prev + (size_t)s0 * fc_stride : nullptr, fc_stride, pw, ph, mul,
-                                I_prev ? I_prev + (size_t)s0 * c->n0 : nullptr, I_prev ? c->R0s[s0 & 1] : nullptr};
+            const BandUpdate bu{flow_prev ? flow_prev + (size_t)s0 * fc_stride : nullptr, fc_stride, pw, ph, mul};
             if (p.J > 1) {
                 sweeps_band_major(c, ss, kid, Min, Mout, ms, r0, r1, rs, 1, l.w, l.h, T, p.J, fo, fstride, &bu, true,
                                   (c->band_phase && (s0 & 1) && p.J >= c->band_phase) ? 1 : 0);
@@ -1116,7 +1087,7 @@ static int layer_sweeps(mav_ctx* c, hipStream_t st, int k, int g, const float* r
 // Otherwise, when the 2 g layer images are small (merge_frames), prev and next go through ONE blur and ONE expansion launch of 2 g
 // images instead of two of g: a group of one or two pairs is bound by launch latency, not by bytes.
 static void layer_expansions(mav_ctx* c, hipStream_t st, int k, const uint8_t* prev, const uint8_t* next, int g, bool seq, float* I, float* R,
-                             const float** r0, const float** r1, bool prev_by_band = false)
+                             const float** r0, const float** r1)
 {
     mav_ctx::WorkSet& w = c->ws;
     const size_t n0 = c->n0;
@@ -1131,16 +1102,6 @@ static void layer_expansions(mav_ctx* c, hipStream_t st, int k, const uint8_t* p
     }
     float* R1 = R + 5 * n0 * (size_t)g;
     *r0 = R; *r1 = R1;
-    if (prev_by_band) {       // layer images of prev (slots 0 .. g - 1) and next (g .. 2 g - 1); expansions of the NEXT frames only
-        const uint8_t* img[2] = {prev, next};
-        for (int i = 0; i < 2; i++) {
-            ProfScope ps(c, K_BLUR_RESIZE, st);
-            launch_blur_resize(st, img[i], nullptr, 0, n0, g, c->W, c->H, l.w, l.h, blur_of(c, l), w.Htmp, c->htmp_stride, I + (size_t)i * g * n0, n0);
-        }
-        ProfScope ps(c, K_POLYEXP, st);
-        launch_polyexp(st, I + (size_t)g * n0, n0, g, l.w, l.h, c->pc, R1, 5 * n0);
-        return;
-    }
     // (the two-pass blur's scratch holds g + 1 frames)
     const bool no_tmp = !blur_resize_needs_tmp(prev, next, n0, c->W, c->H, l.w, l.h, blur_of(c, l), I, n0);
     const bool merge_frames = (no_tmp || 2 * g <= g + 1) && (size_t)2 * g * l.w * l.h * sizeof(float) <= ((size_t)48 << 20);
@@ -1282,17 +1243,8 @@ static int flow_group(mav_ctx* c, const uint8_t* prev, const uint8_t* next, int 
     }
     const float *r0 = nullptr, *r1 = nullptr;
     for (int k = k_top; k >= 0; k--) {
-        // "prev_by_band": finest layer, independent pairs, when its sweeps run two pairs in flight over bands (plan_sweeps)
-        bool by_band = false;
-        if (c->prev_by_band && k == 0 && !seq && c->R0s[0]) {
-            float* fd = flow_out;
-            const bool ok = blur_iter_bands_ok(c->layers[0].w, c->fb.winsize, 5 * n0, 5 * n0, 2 * n0, w.Ma, w.Mb, c->R0s[0], w.R, fd);
-            const SweepPlan p = plan_sweeps(c, 0, g, ok);
-            by_band = p.mode == SW_TWO_PAIRS && p.J > 1;
-        }
-        layer_expansions(c, st, k, prev, next, g, seq, w.I, w.R, &r0, &r1, by_band);
-        CHK(layer_sweeps(c, st, k, g, r0, r1, 5 * n0, flow_prev, fp_stride, pw, ph, k ? w.fc[k & 1] : flow_out, k ? fc_stride : 2 * n0, w.Ma, w.Mb, 5 * n0,
-                         by_band ? w.I : nullptr));
+        layer_expansions(c, st, k, prev, next, g, seq, w.I, w.R, &r0, &r1);
+        CHK(layer_sweeps(c, st, k, g, r0, r1, 5 * n0, flow_prev, fp_stride, pw, ph, k ? w.fc[k & 1] : flow_out, k ? fc_stride : 2 * n0, w.Ma, w.Mb, 5 * n0));
         flow_prev = w.fc[k & 1]; fp_stride = fc_stride; pw = c->layers[k].w; ph = c->layers[k].h;
     }
     return MAV_OK;

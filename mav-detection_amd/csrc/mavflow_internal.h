@@ -58,7 +58,7 @@ bool blur_resize_is_fused(int W, int H, int w, int h, int ksize);
 bool blur_resize_needs_tmp(const uint8_t* img, const uint8_t* img2, size_t img_stride, int W, int H, int w, int h, BlurParams bp,
                            const float* out, size_t out_stride);
 void launch_polyexp(hipStream_t st, const float* I, size_t I_stride, int G, int w, int h, const PolyCoef& pc, float* R,
-                    size_t R_stride, int ty0 = 0, int ty1 = -1 /* 16-row tile rows [ty0, ty1) only; ty1 < 0 = the whole layer */);
+                    size_t R_stride);
 // jobs.j[i]: I, R, I_stride, R_stride, w, h filled by the caller; G images per job
 void launch_polyexp_multi(hipStream_t st, PolyJobs jobs, int G, const PolyCoef& pc);
 // jobs.j[i]: out, out_stride, bp, w, h filled by the caller, for layers blur_multi_ok accepts

@@ -354,7 +354,7 @@ def test_options_are_reported_and_validated(mav):
         assert info["layers"][1]["blur"] == "fused" and info["layers"][1]["pairs_per_launch"] == 4
         for name, v in (("band_mb", 40), ("coarse_half", 3), ("strip", 20), ("phi_yloop", 4), ("phi_screen", 0), ("share_m", 0),
                         ("coarse_cache_mb", 100), ("bands", 3), ("group_fine", 2), ("small_batch", 0), ("sweep_write_through", 1),
-                        ("deep_batch", 0), ("coarse_bands", 1), ("band_phase", 2), ("prev_by_band", 0)):
+                        ("deep_batch", 0), ("coarse_bands", 1), ("band_phase", 2)):
             c.set_option(name, v)
             assert c.get_option(name) == v
             assert c.schedule_info(64)[name] == v
@@ -445,17 +445,6 @@ def test_two_pairs_in_flight_give_the_same_flow(mav, size, batch, group):
         for wt in (0, 1, -1):                        # the sweeps' M' through plain or write-through (sc1) stores: the same values either way
             c.set_option("sweep_write_through", wt)
             assert np.array_equal(c.farneback(prev, nxt), ref), wt
-        # "prev_by_band" (default 1): the prev frame's expansion built band by band into the stream's own buffer instead of with the group's
-        # batched expansions -- same tile function on the same layer image.  With small bands too (several bands per pair at every size).
-        for pb, mb in ((0, 96), (1, 96), (1, 8), (0, 8), (1, 20)):
-            c.set_option("prev_by_band", pb)
-            c.set_option("band_mb", mb)
-            for rep in range(2):
-                out = c.farneback(prev, nxt)
-                assert np.array_equal(out, ref), ("prev_by_band", pb, mb, rep, int((out != ref).sum()))
-            assert np.array_equal(c.farneback(prev[1:3], nxt[1:3]), ref[1:3])
-        c.set_option("band_mb", 96)
-        c.set_option("prev_by_band", 1)
         # the profile's interval union: launches of one class overlap, the busy time stays below their sum
         c.profile_enable(True)
         c.farneback(prev, nxt)
