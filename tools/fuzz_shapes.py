@@ -27,6 +27,11 @@ for case in range(n_cases):
         fb.poly_n = po.poly_n = int(rng.choice([5, 7, 8]))
         fb.poly_sigma = po.poly_sigma = float(rng.choice([1.1, 1.2, 1.5]))
     B = int(rng.integers(1, 4))
+    if case % 11 == 10:                                                            # a many-layer pyramid on a larger frame, several groups per call
+        W, H = int(rng.integers(100, 400)) * 4, int(rng.integers(400, 1000))      # (deep layers once per call, two-pass blur chunks, 64 x 8 tiles)
+        fb.pyr_scale = po.pyr_scale = float(rng.choice([0.4, 0.5]))
+        fb.levels = po.levels = int(rng.integers(3, 6))
+        B = int(rng.integers(3, 7))
     prev = rng.integers(0, 256, (B, H, W)).astype(np.uint8) if case % 7 == 6 else None
     if prev is None:
         pairs = [synth.make_pair(W, H, case * 10 + b, k=0.02, patch=False)[:2] for b in range(B)]
@@ -42,6 +47,8 @@ for case in range(n_cases):
         run = np.concatenate([prev, nxt[-1:]])
         if B > 1:
             c.set_option("group", int(rng.integers(1, B + 1)))
+        # ... and the call cut into groups differently (several groups: the deep layers then run once per call) the one-group flow
+        assert np.array_equal(c.farneback(prev, nxt), out["flow"]), (case, W, H, "groups")
         two = c.farneback(run[:-1].copy(), run[1:].copy())
         assert np.array_equal(c.farneback_sequence(run), two), (case, W, H, "sequence")
     for b in range(B):
