@@ -637,7 +637,7 @@ extern "C" int mav_mem_info(mav_ctx* c, size_t* dev_free, size_t* dev_total, siz
         if (c->foe_sc.cand) n += sizeof(double) * 2 * (size_t)c->foe_sc_n * B;
         n += B * (sizeof(double) * 2 + sizeof(int32_t) * 4 + sizeof(unsigned long long) * 4 + sizeof(int) + sizeof(DerotParams) + sizeof(int) +
                   sizeof(unsigned long long) + sizeof(unsigned) * 2);
-        for (const auto& l : c->layers) n += sizeof(float) * l.ksize;
+        for (const auto& l : c->layers) n += sizeof(float) * l.ksize + (l.coord ? sizeof(int) * 2 * (size_t)(l.w + l.h) : 0);
         for (const auto& b : c->scratch) n += b.cap;
         *ctx_bytes = n;
     }
