@@ -82,3 +82,24 @@ def test_1080p_flow_tracks_the_analytic_field(ctx1080):
     inner = np.hypot(truth[..., 0], truth[..., 1]) < 3.0
     inner[H // 4 - 40:H // 4 + 64, W // 4 - 40:W // 4 + 64] = False
     assert inner.mean() > 0.1 and err[inner].mean() < 0.15, (inner.mean(), err[inner].mean())
+
+
+def test_reference_capture_size_1920x1024(mav, fb_oracle):
+    """The reference's own sequences are AirSim captures at 1920 x 1024 (etc/settings.json:17-18; FlowNet2 needs multiples of 64):
+    68 -> 64 tile rows, another band split.  Whole chain of three pairs (groups of 2 + 1) against the oracle, default schedule."""
+    from mavflow import _lib
+    w, h, B = 1920, 1024, 3
+    pairs = [synth.make_pair(w, h, 30 + b) for b in range(B)]
+    prev, nxt = np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
+    smp = np.stack([synth.foe_samples(w, h, b) for b in range(B)])
+    with _lib.Context(w, h, B) as c:
+        c.set_option("group", 2)
+        out = c.process_batch(prev, nxt, smp)
+        assert c.schedule_info(B)["layers"][0]["bands"] == 2
+    for b in range(B):
+        ref = fb_oracle.calc(prev[b], nxt[b])
+        e = np.hypot(out["flow"][b, ..., 0] - ref[..., 0], out["flow"][b, ..., 1] - ref[..., 1])
+        assert e.mean() <= 1e-2 and np.percentile(e, 99.9) <= 1e-1, (b, e.mean(), e.max())
+        chain = fo.run_chain(out["flow"][b], smp[b])
+        assert tuple(out["results"][b]["foe"]) == tuple(chain["foe"]) and tuple(out["results"][b]["box"]) == tuple(chain["box"])
+        assert np.array_equal(out["mask_fixed"][b], chain["fixed"]) and np.array_equal(out["mask_dyn"][b], chain["total"])
