@@ -357,6 +357,9 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="mav_set_option before the run (A/B experiments); repeatable")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 rehearsal on ONE GPU (tests): process group over gloo, every rank on device 0, records exchanged through torch's "
+                         "all-gather of host tensors (RCCL refuses two ranks on one device); the figures it prints are not a scaling measurement")
     ap.add_argument("--no-configs", action="store_true", help="skip the extra BASELINE configuration legs (C2: 1280x720 batch 1; C5 share: 3840x2160, 5 levels, batch 16)")
     args = ap.parse_args()
 
@@ -384,7 +387,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist, rank, world, local_rank = mdist.init_process_group("nccl")
+        dist, rank, world, local_rank = mdist.init_process_group("gloo" if args.rehearse_on_one_gpu else "nccl")
+        if args.rehearse_on_one_gpu:
+            local_rank = 0
+    tdev = "cpu" if args.rehearse_on_one_gpu else "cuda"           # where the torch tensors of the process-group collectives live
 
     import numpy as np
     from mavflow import _lib, synth
@@ -421,6 +427,8 @@ def main():
     t_local = t_all = None
     if dist is not None:
         try:
+            if args.rehearse_on_one_gpu:
+                raise RuntimeError("rehearsal on one GPU: RCCL cannot hold two ranks on one device")
             uid = torch.zeros(128, dtype=torch.uint8)
             if rank == 0:
                 uid = torch.from_numpy(ctx.comm_unique_id().copy())
@@ -430,8 +438,8 @@ def main():
             exchange = "mav_allgather_results (RCCL ncclAllGather on the context's stream)"
         except Exception as e:                         # noqa: BLE001 -- any failure here must not lose the measurement
             comm, exchange = None, f"torch.distributed.all_gather_into_tensor (library communicator unavailable: {e})"
-            t_local = torch.empty(B * rec, dtype=torch.uint8, device="cuda")
-            t_all = torch.empty(world * B * rec, dtype=torch.uint8, device="cuda")
+            t_local = torch.empty(B * rec, dtype=torch.uint8, device=tdev)
+            t_all = torch.empty(world * B * rec, dtype=torch.uint8, device=tdev)
 
     def run_batch():
         # flow stays in the library's HBM workspace (flow_ptr=None); both threshold masks are written out (1 B/px each),
@@ -468,7 +476,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -478,6 +486,12 @@ def main():
     if comm is not None:                               # the gathered block of this rank must be its own records
         allrec = d_all.download(_lib.RESULT_DTYPE, (world * B,))
         assert allrec[rank * B:(rank + 1) * B].tobytes() == res_last.tobytes(), "all-gathered records differ from the local ones"
+    elif t_all is not None:                            # torch's all-gather (fallback / one-GPU rehearsal): same check on its block
+        allrec = t_all.cpu().numpy().view(_lib.RESULT_DTYPE)
+        assert allrec[rank * B:(rank + 1) * B].tobytes() == res_last.tobytes(), "all-gathered records differ from the local ones"
+    gathered_distinct = None
+    if dist is not None and world > 1:                 # every rank runs different content (frames rolled by 31 px per rank, other samples)
+        gathered_distinct = len({allrec[r * B:(r + 1) * B].tobytes() for r in range(world)})
     if rank == 0 and not args.no_verify:
         verification = verify_last_step(ctx, prev, nxt, samples, res_last, d_mf, d_md, sorted({0, B - 1}), args.levels)
         # ... and EVERY pair of the timed step against the same batch re-run in the plain schedule
@@ -591,6 +605,10 @@ def main():
             out["host_enqueue_is"] = ("wall time of one step's mav_process_batch_dev (+ all-gather) call issued into an idle queue, median of 7 "
                                       "(the *_in_loop figure is the timed loop's enqueue time / steps and includes queue back-pressure); "
                                       "roofline.kernel_launches_per_step_all_classes launches + the fork / join events per step")
+        if gathered_distinct is not None:
+            out["gathered_rank_blocks_distinct"] = gathered_distinct
+        if args.rehearse_on_one_gpu:
+            out["rehearsal"] = f"{world} ranks share ONE GPU, process group over gloo: a functional run of the N > 1 path, not a scaling measurement"
         if world > 1:
             out["scaling_note"] = "per-GPU work fixed (weak); efficiency is the driver's to compute from the per-N values"
         if h2d_ms:
