@@ -95,9 +95,10 @@ int mav_device_count(void);       /* <= 0 when no GPU is visible */
  *   "small_batch"      default 1: a group whose finest-layer working set is at most 200 MB (one 1080p pair, two 720p pairs: a chain of
  *                      launches that each fill a fraction of the chip) gets the layer images of its whole pyramid from ONE launch and
  *                      all polynomial expansions from ONE launch instead of two launches per layer
- *   "deep_batch"       default 1: when a call has more than one group, the layers at the top of the pyramid that are each at most 1/32
- *                      of the frame (layers 2 - 4 of the 3840x2160 / 5-layer preset: latency-bound chains of tiny launches) run ONCE for
- *                      up to 64 pairs of the call before the groups start, instead of once per group
+ *   "deep_batch"       default 1: when a call has more than one group, the coarse layers of the pyramid (every layer of at most
+ *                      1/"deep_frac" of the frame, default 6: all layers above the finest at pyr_scale 0.4) run ONCE for up to 64 pairs of
+ *                      the call before the groups start, instead of once per group; "deep_frac" can be set until the first call that
+ *                      computes flow (MAV_ERR_STATE afterwards)
  *   "coarse_bands"     default 0: 1 = a coarse layer whose per-pair working set exceeds "band_mb" (layer 1 of the 4K preset, 106 MB) is
  *                      swept like the finest layer, pairs alternating between the two streams band by band (measured slower: off)
  *   "band_phase"       default 0; n > 0: in the two-stream schedule the pairs of the second stream use a band partition shifted by half a

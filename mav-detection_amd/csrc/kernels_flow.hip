@@ -855,10 +855,29 @@ bool blur_multi_ok(const uint8_t* img, const uint8_t* img2, size_t img_stride, i
 {
     return blur3_fast_ok(img, img2 ? img2 : img, img_stride, W, H, w, h, bp, out, out_stride) || blur_resize_is_fused(W, H, w, h, bp.ksize);
 }
-void launch_blur_multi(hipStream_t st, const uint8_t* img, const uint8_t* img2, int split, size_t img_stride, int G, int W, int H, BlurJobs jobs)
+void launch_blur_multi(hipStream_t st, const uint8_t* img, const uint8_t* img2, int split, size_t img_stride, int G, int W, int H, BlurJobs jobs,
+                       bool split_by_path)
 {
     if (!img2) { img2 = img; split = G; }
     const int dword_ok = (W % 4 == 0 && img_stride % 4 == 0 && ((uintptr_t)img & 3) == 0 && ((uintptr_t)img2 & 3) == 0) ? 1 : 0;
+    if (split_by_path) {      // many frames per layer (the deep layers of a whole call): one launch per tile code -- a launch that mixes
+                              // them runs every layer at the occupancy of the hungriest path -- instead of one launch in all
+        bool done[MAV_MAX_JOBS] = {false};
+        for (int i = 0; i < jobs.n; i++) {
+            if (done[i]) continue;
+            auto path_of = [&](const BlurJob& J) {
+                if (J.w == W && J.h == H) return -1;
+                const FusedPlan fp = fused_plan(W, H, J.w, J.h, J.bp, dword_ok);
+                return fused_path_of(J.bp, fp.pitch_w, dword_ok);
+            };
+            const int p = path_of(jobs.j[i]);
+            BlurJobs sub{0, 0, {}};
+            for (int k = i; k < jobs.n; k++)
+                if (!done[k] && path_of(jobs.j[k]) == p) { sub.j[sub.n++] = jobs.j[k]; done[k] = true; }
+            launch_blur_multi(st, img, img2, split, img_stride, G, W, H, sub, false);
+        }
+        return;
+    }
     int blocks = 0;
     size_t lds = 0;
     for (int i = 0; i < jobs.n; i++) {

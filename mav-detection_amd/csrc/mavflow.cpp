@@ -224,12 +224,17 @@ struct mav_ctx {
     } ws;
     std::vector<size_t> c_off, c_stride;      // per layer (index 0 unused); c_total = sum of the strides
     size_t c_total = 0;
-    // DEEP LAYERS (deep_layers): layers kd .. top, each at most 1/32 of the frame (layers 2 - 4 of the 4K / 5-layer preset), are
-    // latency-bound chains of tiny launches.  When a call has more than one group they run ONCE for up to deep_cap pairs of the call
-    // (all their images from one launch, all expansions from one launch, sweeps over all pairs) before the groups start; the groups
-    // then begin at layer kd - 1 with the deep flow as their coarser layer.  Buffers of their own, every layer in a compact region.
+    // DEEP LAYERS (deep_layers): layers kd .. top, each at most 1/deep_frac of the frame -- every coarse layer of a 0.4-scale pyramid.
+    // When a call has more than one group they run ONCE for up to deep_cap pairs of the call (their images from one launch per tile code,
+    // all expansions from one launch, sweeps over all pairs in cache-sized sub-groups) before the groups start; the groups then begin at
+    // layer kd - 1 with the deep flow as their coarser layer.  Buffers of their own, every layer in a compact region.
     struct DeepSet { float *I = nullptr, *R = nullptr, *Ma = nullptr, *Mb = nullptr, *f[2] = {nullptr, nullptr}; } deep;
     int kd = 0, deep_cap = 0;                 // kd = 0: no deep layer
+    // option "deep_frac" (before the first flow call): a layer is deep when its pixels x deep_frac <= the frame's.  6: every coarse layer
+    // of a 0.4-scale pyramid (layer 1 is 0.16 of the frame).  Measured with 32 (layers 2 - 4 of the 4K preset only) vs 6: 1080p, 64 pairs
+    // 2 579 - 2 637 vs 2 653 - 2 686 pairs/s (+2.4 %: layer 1's sixteen sub-groups of 4 pairs run back to back for the whole call instead
+    // of four per group behind a fork / join each); 4K 607 - 609 vs 609 - 610 (profiles/r04/ab_deep_frac.log)
+    int deep_frac = 6;
     bool deep_batch = true;                   // option "deep_batch"
     int band_phase = 0;                       // option "band_phase": n > 0 = the second stream's pairs use a partition shifted by half a band
                                               // when a pair has at least n bands (sweeps_band_major); 0 = never (default: measured slower)
@@ -509,8 +514,8 @@ extern "C" int mav_create(mav_ctx** out, int device, int W, int H, int max_batch
         c->c_off[k] = c->c_total;
         c->c_total += c->c_stride[k];
     }
-    for (int k = levels; k >= 2; k--)                   // deep layers: the top of the pyramid, every layer at most 1/32 of the frame
-        if ((size_t)c->layers[k].w * c->layers[k].h * 32 <= c->n0) c->kd = k; else break;
+    for (int k = levels; k >= 1; k--)                   // deep layers: the top of the pyramid, every layer at most 1/deep_frac of the frame
+        if ((size_t)c->layers[k].w * c->layers[k].h * (size_t)c->deep_frac <= c->n0) c->kd = k; else break;
     c->deep_cap = max_batch < 64 ? max_batch : 64;
     c->htmp_stride = (size_t)H * W;                    // any layer (even layer 0 when its fast form does not apply) fits
     // group: pairs per launch for everything but the finest layer's sweeps (see flow_group).
@@ -550,7 +555,7 @@ static const OptionDesc kOptions[] = {
     {"group", 1, 1 << 20}, {"group_fine", 0, 1 << 20}, {"bands", 0, 8}, {"pairs_in_flight", 1, 2}, {"band_mb", 8, 1 << 20},
     {"coarse_cache_mb", 0, 1 << 20}, {"coarse_half", 0, 1 << 20}, {"share_m", 0, 1}, {"share_frames", 0, 1}, {"strip", 0, 1 << 20},
     {"phi_screen", 0, 1}, {"phi_yloop", 0, 1 << 20}, {"small_batch", 0, 1}, {"sweep_write_through", -1, 1}, {"deep_batch", 0, 1},
-    {"coarse_bands", 0, 1}, {"band_phase", 0, 64},
+    {"coarse_bands", 0, 1}, {"band_phase", 0, 64}, {"deep_frac", 1, 1 << 20},
 };
 static long* option_slot(mav_ctx* c, const char* name, long* tmp)
 {
@@ -559,7 +564,7 @@ static long* option_slot(mav_ctx* c, const char* name, long* tmp)
         {"group", c->group}, {"group_fine", c->group_fine}, {"bands", c->bands}, {"pairs_in_flight", c->pairs_in_flight},
         {"band_mb", c->pif_band_mb}, {"coarse_cache_mb", c->coarse_cache_mb}, {"coarse_half", c->coarse_half}, {"share_m", c->share_m},
         {"share_frames", c->share_frames}, {"strip", c->strip}, {"phi_screen", c->phi_screen}, {"phi_yloop", c->phi_yloop},
-        {"small_batch", c->small_batch}, {"sweep_write_through", c->sweep_wt}, {"deep_batch", c->deep_batch}, {"coarse_bands", c->coarse_bands}, {"band_phase", c->band_phase},
+        {"small_batch", c->small_batch}, {"sweep_write_through", c->sweep_wt}, {"deep_batch", c->deep_batch}, {"coarse_bands", c->coarse_bands}, {"band_phase", c->band_phase}, {"deep_frac", c->deep_frac},
     };
     for (auto& e : cur) if (!strcmp(e.n, name)) { *tmp = e.v; return tmp; }
     return nullptr;
@@ -607,6 +612,12 @@ extern "C" int mav_set_option(mav_ctx* c, const char* name, long value)
     else if (!strcmp(name, "deep_batch")) c->deep_batch = v != 0;
     else if (!strcmp(name, "coarse_bands")) c->coarse_bands = v != 0;
     else if (!strcmp(name, "band_phase")) c->band_phase = v;
+    else if (!strcmp(name, "deep_frac")) {
+        if (c->ws_ready) return fail(MAV_ERR_STATE, "deep_frac must be set before the first call that computes flow");
+        c->deep_frac = v; c->kd = 0;
+        for (int k = (int)c->layers.size() - 1; k >= 1; k--)
+            if ((size_t)c->layers[k].w * c->layers[k].h * (size_t)v <= c->n0) c->kd = k; else break;
+    }
     return MAV_OK;
 }
 
@@ -1151,7 +1162,7 @@ static void pyramid_multi(mav_ctx* c, hipStream_t st, const uint8_t* prev, const
     const size_t n0 = c->n0;
     BlurJobs bj{0, 0, {}};
     PolyJobs pj{0, 0, {}};
-    auto flush_blur = [&]() { if (bj.n) { ProfScope ps(c, K_BLUR_RESIZE, st); launch_blur_multi(st, prev, img2, split, n0, F, c->W, c->H, bj); bj.n = 0; } };
+    auto flush_blur = [&]() { if (bj.n) { ProfScope ps(c, K_BLUR_RESIZE, st); launch_blur_multi(st, prev, img2, split, n0, F, c->W, c->H, bj, F > 8); bj.n = 0; } };
     auto flush_poly = [&]() { if (pj.n) { ProfScope ps(c, K_POLYEXP, st); launch_polyexp_multi(st, pj, F, c->pc); pj.n = 0; } };
     for (int k = k_lo; k <= k_hi; k++) {
         const Layer& l = c->layers[k];

@@ -64,7 +64,8 @@ void launch_polyexp_multi(hipStream_t st, PolyJobs jobs, int G, const PolyCoef& 
 // jobs.j[i]: out, out_stride, bp, w, h filled by the caller, for layers blur_multi_ok accepts
 bool blur_multi_ok(const uint8_t* img, const uint8_t* img2, size_t img_stride, int W, int H, int w, int h, BlurParams bp, const float* out,
                    size_t out_stride);
-void launch_blur_multi(hipStream_t st, const uint8_t* img, const uint8_t* img2, int split, size_t img_stride, int G, int W, int H, BlurJobs jobs);
+void launch_blur_multi(hipStream_t st, const uint8_t* img, const uint8_t* img2, int split, size_t img_stride, int G, int W, int H, BlurJobs jobs,
+                       bool split_by_path = false /* one launch per tile code (fused_path_of) instead of one for all jobs */);
 // flow_prev == nullptr: zero initial flow. Otherwise flow = resize(prev (ph x pw x 2))*mul, evaluated inline.
 void launch_update_matrices(hipStream_t st, const float* R0, const float* R1, size_t R_stride, const float* flow_prev,
                             size_t fp_stride, int pw, int ph, float mul, int G, int w, int h, float* M, size_t M_stride,

@@ -354,7 +354,7 @@ def test_options_are_reported_and_validated(mav):
         assert info["layers"][1]["blur"] == "fused" and info["layers"][1]["pairs_per_launch"] == 4
         for name, v in (("band_mb", 40), ("coarse_half", 3), ("strip", 20), ("phi_yloop", 4), ("phi_screen", 0), ("share_m", 0),
                         ("coarse_cache_mb", 100), ("bands", 3), ("group_fine", 2), ("small_batch", 0), ("sweep_write_through", 1),
-                        ("deep_batch", 0), ("coarse_bands", 1), ("band_phase", 2)):
+                        ("deep_batch", 0), ("coarse_bands", 1), ("band_phase", 2), ("deep_frac", 32)):
             c.set_option(name, v)
             assert c.get_option(name) == v
             assert c.schedule_info(64)[name] == v
@@ -365,6 +365,12 @@ def test_options_are_reported_and_validated(mav):
         for name, v in (("pairs_in_flight", 3), ("bands", 9), ("group", 0), ("no_such_option", 1), ("recompute", 1), ("pipeline", 1)):
             with pytest.raises(ValueError):
                 c.set_option(name, v)
+    with _lib.Context(640, 480, 2) as c:                                 # the deep set is sized by deep_frac: fixed once flow has been computed
+        assert c.schedule_info(2)["deep_frac"] == 6
+        prev, nxt = synth.make_batch(640, 480, 2, distinct=2)
+        c.farneback(prev, nxt)
+        with pytest.raises(_lib.MavflowError):
+            c.set_option("deep_frac", 32)
 
 
 def test_winsize_beyond_the_fast_kernel(mav, fb_oracle):
@@ -470,6 +476,8 @@ def test_deep_layers_once_per_call_and_banded_coarse_layers_are_bit_identical(ma
     with _lib.Context(W, H, batch, _lib.fb_defaults(levels=levels)) as c:
         c.set_option("group", group)
         c.set_option("band_mb", band_mb)
+        if size == (1000, 562):
+            c.set_option("deep_frac", 32)                    # (only layers 2 .. are deep then: the groups start at layer 1)
         for name in ("deep_batch", "coarse_bands"):
             c.set_option(name, 0)
         c.set_option("pairs_in_flight", 1)
@@ -485,8 +493,8 @@ def test_deep_layers_once_per_call_and_banded_coarse_layers_are_bit_identical(ma
             c.set_option("coarse_bands", cb)
             info = c.schedule_info(batch)
             n_layers = len(info["layers"])
-            if deep and n_layers > 2:
-                assert info["deep_layers_from"] >= 2 and info["deep_pairs"] == batch
+            if deep and n_layers > 1:
+                assert info["deep_layers_from"] == (2 if size == (1000, 562) else 1) and info["deep_pairs"] == batch
             w1, h1 = info["layers"][1]["w"], info["layers"][1]["h"]
             big = w1 % 4 == 0 and w1 * h1 * 80 > (band_mb << 20) and ((h1 + 15) // 16) // 12 >= 2
             assert big == (size in ((1920, 1080), (3840, 2160)))
