@@ -71,3 +71,39 @@ def test_helper_context_cache_is_bounded_and_closes_what_it_drops(mav):
     assert list(im_helpers._ctx_cache) == [sizes[2], sizes[1]]    # a hit moves to the back
     c = im_helpers._ctx(96, 72, batch=4)                          # a larger batch replaces (and closes) the cached context
     assert c.max_batch == 4 and seen[2].h is None
+
+
+def test_two_contexts_in_two_threads_are_independent(mav):
+    """include/mavflow.h: a mav_ctx is single-threaded, distinct contexts are independent.  Two host threads, each with a context of its
+    own (different frame sizes, hence different streams, workspaces, tables and option sets), run the fused path concurrently; every
+    result must equal what the same context gives alone."""
+    import threading
+    from mavflow import _lib
+    jobs = []
+    for (W, H, B, levels) in ((640, 480, 3, 1), (1000, 562, 2, 3)):
+        prev, nxt = synth.make_batch(W, H, B, distinct=B)
+        smp = np.stack([synth.foe_samples(W, H, b) for b in range(B)])
+        with _lib.Context(W, H, B, _lib.fb_defaults(levels=levels)) as c:
+            ref = c.process_batch(prev, nxt, smp)
+        jobs.append((W, H, B, levels, prev, nxt, smp, ref))
+    errors = []
+
+    def work(job):
+        W, H, B, levels, prev, nxt, smp, ref = job
+        try:
+            with _lib.Context(W, H, B, _lib.fb_defaults(levels=levels)) as c:
+                c.set_option("group", 1 + (W % 2))
+                for rep in range(6):
+                    out = c.process_batch(prev, nxt, smp)
+                    assert np.array_equal(out["flow"], ref["flow"]), (W, rep)
+                    assert out["results"].tobytes() == ref["results"].tobytes(), (W, rep)
+                    assert np.array_equal(out["mask_fixed"], ref["mask_fixed"]) and np.array_equal(out["mask_dyn"], ref["mask_dyn"])
+        except Exception as e:                         # noqa: BLE001 -- reported by the main thread
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(j,)) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
