@@ -101,6 +101,9 @@ int mav_device_count(void);       /* <= 0 when no GPU is visible */
  *                      computes flow (MAV_ERR_STATE afterwards)
  *   "coarse_bands"     default 0: 1 = a coarse layer whose per-pair working set exceeds "band_mb" (layer 1 of the 4K preset, 106 MB) is
  *                      swept like the finest layer, pairs alternating between the two streams band by band (measured slower: off)
+ *   "band_skew"        default -1: the band boundaries are moved down by (iterations - 1) / 2 tile rows -- sweep `it` shifts every
+ *                      boundary up by `it` rows, so this gives every band the same average size over its sweeps (even launches, even
+ *                      cache footprints); n >= 0: by n rows (0 = equal bands)
  *   "band_phase"       default 0; n > 0: in the two-stream schedule the pairs of the second stream use a band partition shifted by half a
  *                      band whenever a pair has at least n bands, so that the two streams do not build their bands' initial M (HBM-bound)
  *                      at the same moments (measured slower: the lockstep of the two streams protects the Infinity Cache)

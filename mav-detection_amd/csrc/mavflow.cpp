@@ -236,7 +236,8 @@ struct mav_ctx {
     // of four per group behind a fork / join each); 4K 607 - 609 vs 609 - 610 (profiles/r04/ab_deep_frac.log)
     int deep_frac = 6;
     bool deep_batch = true;                   // option "deep_batch"
-    bool band_skew = true;                    // option "band_skew": band boundaries compensated for the sweeps' skew (sweeps_band_major)
+    int band_skew = -1;                       // option "band_skew": tile rows the band boundaries move down to compensate the sweeps' skew
+                                              // (sweeps_band_major); -1 = (iterations - 1) / 2, 0 = equal bands
     int band_phase = 0;                       // option "band_phase": n > 0 = the second stream's pairs use a partition shifted by half a band
                                               // when a pair has at least n bands (sweeps_band_major); 0 = never (default: measured slower)
     bool coarse_bands = false;                // option "coarse_bands": a coarse layer whose per-pair working set exceeds band_mb is swept like the finest one
@@ -556,7 +557,7 @@ static const OptionDesc kOptions[] = {
     {"group", 1, 1 << 20}, {"group_fine", 0, 1 << 20}, {"bands", 0, 8}, {"pairs_in_flight", 1, 2}, {"band_mb", 8, 1 << 20},
     {"coarse_cache_mb", 0, 1 << 20}, {"coarse_half", 0, 1 << 20}, {"share_m", 0, 1}, {"share_frames", 0, 1}, {"strip", 0, 1 << 20},
     {"phi_screen", 0, 1}, {"phi_yloop", 0, 1 << 20}, {"small_batch", 0, 1}, {"sweep_write_through", -1, 1}, {"deep_batch", 0, 1},
-    {"coarse_bands", 0, 1}, {"band_phase", 0, 64}, {"band_skew", 0, 1}, {"deep_frac", 1, 1 << 20},
+    {"coarse_bands", 0, 1}, {"band_phase", 0, 64}, {"band_skew", -1, 64}, {"deep_frac", 1, 1 << 20},
 };
 static long* option_slot(mav_ctx* c, const char* name, long* tmp)
 {
@@ -613,7 +614,7 @@ extern "C" int mav_set_option(mav_ctx* c, const char* name, long value)
     else if (!strcmp(name, "deep_batch")) c->deep_batch = v != 0;
     else if (!strcmp(name, "coarse_bands")) c->coarse_bands = v != 0;
     else if (!strcmp(name, "band_phase")) c->band_phase = v;
-    else if (!strcmp(name, "band_skew")) c->band_skew = v != 0;
+    else if (!strcmp(name, "band_skew")) c->band_skew = v;
     else if (!strcmp(name, "deep_frac")) {
         if (c->ws_ready) return fail(MAV_ERR_STATE, "deep_frac must be set before the first call that computes flow");
         c->deep_frac = v; c->kd = 0;
@@ -985,7 +986,7 @@ static void sweeps_band_major(mav_ctx* c, hipStream_t st, int kid, float* Ma, fl
         // Sweep `it` shifts every boundary up by `it` tile rows: over a band's sweeps the first band loses (I - 1) / 2 rows on average
         // and the last one gains as many.  Boundaries moved down by that amount give every band the same AVERAGE size -- launches and
         // cache footprints stay even (option "band_skew"; 1080p: first band 38 of 68 tile rows instead of 34; equal split: 0).
-        int b = (int)((long long)T * j / J) + (c->band_skew ? (I - 1) / 2 : 0);
+        int b = (int)((long long)T * j / J) + (c->band_skew < 0 ? (I - 1) / 2 : c->band_skew);
         const int lo = j, hi = T - (NBands - j);             // at least one tile row per band
         return b < lo ? lo : (b > hi ? hi : b);
     };

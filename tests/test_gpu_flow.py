@@ -354,7 +354,7 @@ def test_options_are_reported_and_validated(mav):
         assert info["layers"][1]["blur"] == "fused" and info["layers"][1]["pairs_per_launch"] == 4
         for name, v in (("band_mb", 40), ("coarse_half", 3), ("strip", 20), ("phi_yloop", 4), ("phi_screen", 0), ("share_m", 0),
                         ("coarse_cache_mb", 100), ("bands", 3), ("group_fine", 2), ("small_batch", 0), ("sweep_write_through", 1),
-                        ("deep_batch", 0), ("coarse_bands", 1), ("band_phase", 2), ("deep_frac", 32)):
+                        ("deep_batch", 0), ("coarse_bands", 1), ("band_phase", 2), ("deep_frac", 32), ("band_skew", 0)):
             c.set_option(name, v)
             assert c.get_option(name) == v
             assert c.schedule_info(64)[name] == v
@@ -515,6 +515,13 @@ def test_deep_layers_once_per_call_and_banded_coarse_layers_are_bit_identical(ma
                 out = c.farneback(prev, nxt)
                 assert np.array_equal(out, ref), ("band_phase", bp, mb, rep, int((out != ref).sum()))
         c.set_option("band_mb", band_mb)
+        c.set_option("band_phase", 0)
+        # "band_skew": boundaries moved down by (iterations - 1) / 2 tile rows (default) so that every band has the same average size over
+        # its sweeps; 0 = equal bands, other shifts for the test -- any monotone partition gives the same flow
+        for bs in (0, 2, 7, -1):
+            c.set_option("band_skew", bs)
+            out = c.farneback(prev, nxt)
+            assert np.array_equal(out, ref), ("band_skew", bs, int((out != ref).sum()))
         c.set_option("band_phase", 1)
         two = c.process_batch(prev, nxt, smp)
         for key in ("flow", "mask_fixed", "mask_dyn"):
