@@ -910,7 +910,7 @@ static SweepPlan plan_sweeps(const mav_ctx* c, int k, int g, bool bands_ok)
     p.m_per_sub = p.sub < g;
     const size_t ws_pair = (size_t)l.w * l.h * 80, band_bytes = (size_t)c->pif_band_mb << 20;
     // A COARSE layer whose per-pair working set exceeds a band (layer 1 of the 4K preset: 1536 x 864, 106 MB) is swept exactly like the
-    // finest one: pairs alternate between the two streams, each band-major, so that the two pairs in flight occupy 2 x <= 86 MB of the
+    // finest one: pairs alternate between the two streams, each band-major, so that the two pairs in flight occupy 2 x <= band_mb of the
     // Infinity Cache instead of 2 x 106 MB (option "coarse_bands").
     const bool big_coarse = k > 0 && c->coarse_bands && bands_ok && ws_pair > band_bytes && T / (I + 2) >= 2;
     if (big_coarse) { p.sub = 1; p.m_per_sub = true; }
@@ -930,7 +930,7 @@ static SweepPlan plan_sweeps(const mav_ctx* c, int k, int g, bool bands_ok)
         // and pair_stream -- and ping-pongs M through slot s & 1.  The two streams never wait for each other inside the group
         // (different pairs: no dependency; one fork and one join event per group), so one stream's launches fill the kernel
         // boundaries and the fill / drain of the other's.  What keeps this inside the 256 MB Infinity Cache is the band-major order:
-        // each pair is swept (and its initial M built) band by band, bands of at most 86 MB of working set -- 2 bands at 1080p, 8 at
+        // each pair is swept (and its initial M built) band by band, bands of at most band_mb (96 MB) of working set -- 2 bands at 1080p, 7 at
         // 3840x2160 -- so the hot set is 2 x 83 MB, what ONE whole 1080p pair occupies in the one-stream schedule.  Measured
         // (profiles/r02/ab_two_pairs*.log): 1080p 25.9 - 26.3 vs 27.1 - 27.4 ms per 64 pairs, 4K 28.7 vs 30.1 ms per 16 pairs; two full
         // pairs without bands 28.6 ms, three or four streams 27.9 - 28.1 ms.  Same tiles, same arithmetic as every other schedule:
