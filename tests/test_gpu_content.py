@@ -4,13 +4,14 @@ The GPU path stores and sums in float32 (sliding differences inside a tile) wher
 accumulates the box sums in float64; flat areas, step edges, noise, low contrast and saturation are where that could show.  The
 reference's subject is a small drone against sky (/root/reference/src/processor.py:314-317 sky mask, :333-341 thresholds).
 
-Per case, through the C-ABI (mav_process_batch): flow finite and inside the EPE gate against the C oracle (mean <= 1e-2 px,
-p99.9 <= 1e-1 px; the measured mean / p99.9 / max are printed), and FoE, both masks and the box bit-exact against the numpy
+Per case, through the C-ABI (mav_process_batch): flow finite and inside the EPE gate against the C oracle (oracle/tolerances.py: mean <= 1e-4 px,
+p99.9 <= 1e-2 px, max <= 0.15 px; the measured mean / p99.9 / max are printed), and FoE, both masks and the box bit-exact against the numpy
 chain (oracle/foe_oracle.py) evaluated on the GPU's own flow."""
 import numpy as np
 import pytest
 
 from oracle import foe_oracle as fo
+from oracle.tolerances import check_flow
 from mavflow import synth
 
 pytestmark = pytest.mark.gpu
@@ -93,8 +94,7 @@ def test_content(ctx1080, fb_oracle, name):
     e = np.hypot(flow[..., 0] - ref[..., 0], flow[..., 1] - ref[..., 1])
     print(f"\n{name}: EPE vs the C oracle mean {e.mean():.3e}  p99.9 {np.percentile(e, 99.9):.3e}  max {e.max():.3e}  "
           f"(|flow| max {np.abs(ref).max():.2f} px)")
-    assert e.mean() <= 1e-2, (name, e.mean())
-    assert np.percentile(e, 99.9) <= 1e-1, (name, np.percentile(e, 99.9))
+    check_flow(flow, ref, name)
     chain = fo.run_chain(flow, smp[0])
     r = out["results"][0]
     assert tuple(r["foe"]) == tuple(chain["foe"]), name
@@ -117,4 +117,4 @@ def test_content_4k_five_layers(mav, fb_oracle, name):
     ref = fb_oracle.calc(f0, f1, fbo.default_params(levels=5))
     e = np.hypot(flow[..., 0] - ref[..., 0], flow[..., 1] - ref[..., 1])
     print(f"\n{name} at 4K / 5 layers: EPE vs the C oracle mean {e.mean():.3e}  p99.9 {np.percentile(e, 99.9):.3e}  max {e.max():.3e}")
-    assert e.mean() <= 1e-2 and np.percentile(e, 99.9) <= 1e-1, (name, e.mean(), np.percentile(e, 99.9))
+    check_flow(flow, ref, name)

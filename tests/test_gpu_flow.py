@@ -3,7 +3,7 @@
 
 Tolerances (floating point; the CPU path mixes f32 storage with f64 accumulators, the GPU path is f32 throughout):
   stages    absolute, stated per test
-  flow      end-point error vs the oracle: mean <= 1e-2 px, p99.9 <= 1e-1 px   (north_star "stated EPE tolerance")
+  flow      end-point error vs the oracle: mean <= 1e-4 px, p99.9 <= 1e-2 px, max <= 0.15 px: oracle/tolerances.py   (tightened to the measured level; north_star "stated EPE tolerance")
 PARITY UNPINNED vs cv2 itself: OpenCV is not installable here (see oracle/farneback_oracle.c)."""
 import os
 
@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 from mavflow import synth
+from oracle.tolerances import check_flow
 
 pytestmark = pytest.mark.gpu
 
@@ -113,11 +114,7 @@ def test_blur_iter(ctx640, fb_oracle, pair640, k, update):
 
 
 def _check_flow(got, exp, tag=""):
-    e = epe(got, exp)
-    assert np.isfinite(got).all()
-    assert e.mean() <= 1e-2, (tag, e.mean())
-    assert np.percentile(e, 99.9) <= 1e-1, (tag, np.percentile(e, 99.9))
-    return e
+    return check_flow(got, exp, tag)
 
 
 def test_flow_640x480(ctx640, fb_oracle, pair640):

@@ -11,13 +11,10 @@ import numpy as np
 import pytest
 
 from oracle import foe_oracle as fo
+from oracle.tolerances import check_flow
 from mavflow import synth
 
 pytestmark = pytest.mark.gpu
-
-
-def epe(a, b):
-    return np.hypot(a[..., 0] - b[..., 0], a[..., 1] - b[..., 1])
 
 
 class TimedRun:
@@ -72,8 +69,7 @@ def test_c3_1080p_batch64_as_timed(mav, fb_oracle):
         for b in (0, 7, 8, 37, 63):
             flow = check_pair_against_oracle(ctx, b, smp[b], res, mf, md)
             if b in (0, 37):
-                e = epe(flow, fb_oracle.calc(prev[b], nxt[b]))
-                assert e.mean() <= 1e-2 and np.percentile(e, 99.9) <= 1e-1, (b, e.mean(), e.max())
+                check_flow(flow, fb_oracle.calc(prev[b], nxt[b]), b)
         for b in range(B):                                             # box == extents of the fixed mask, every pair
             assert tuple(res[b]["box"]) == fo.simple_bounding_box(mf[b]), b
         # shifted copies of a base pair (make_batch) see the FoE shifted by the same (13 s, 7 s): a second, oracle-free check
@@ -94,8 +90,7 @@ def test_c2_720p_batch1_full_chain(mav, fb_oracle):
         t = TimedRun(ctx, prev, nxt, smp)
         res, mf, md = t.run()
         flow = check_pair_against_oracle(ctx, 0, smp[0], res, mf, md)
-        e = epe(flow, fb_oracle.calc(f0, f1))
-        assert e.mean() <= 1e-2 and np.percentile(e, 99.9) <= 1e-1, (e.mean(), e.max())
+        check_flow(flow, fb_oracle.calc(f0, f1), "C2")
         assert mf[0].any() and md[0].any()
         assert abs(res[0]["foe"][0] - 0.55 * W) < 30 and abs(res[0]["foe"][1] - 0.45 * H) < 30
         # the host-pointer entry point (what the reference-shaped loop calls) gives the same answer
@@ -118,8 +113,7 @@ def test_c5_4k_five_layers_batch16_full_chain(mav, fb_oracle):
         t = TimedRun(ctx, prev, nxt, smp)
         res, mf, md = t.run()
         flow = check_pair_against_oracle(ctx, 3, smp[3], res, mf, md)
-        e = epe(flow, fb_oracle.calc(prev[3], nxt[3], fbo.default_params(levels=5)))
-        assert e.mean() <= 1e-2 and np.percentile(e, 99.9) <= 1e-1, (e.mean(), e.max())
+        check_flow(flow, fb_oracle.calc(prev[3], nxt[3], fbo.default_params(levels=5)), "C5 share")
         check_pair_against_oracle(ctx, 12, smp[12], res, mf, md)       # a pair from the middle of the batch
         for b in range(B):
             assert tuple(res[b]["box"]) == fo.simple_bounding_box(mf[b]), b
