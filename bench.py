@@ -333,6 +333,67 @@ def run_config_leg(name, W, H, B, levels, calls, pairs_to_check, verify=True, ce
     return out
 
 
+def api_loop_leg(W=1920, H=1080, batch=64, n_batches=6, n_unbatched=96, staged=False, breakdown=False):
+    """The door north_star says users come through: the reference-shaped loops of mavflow.processor on a pre-generated synthetic
+    dataset -- host numpy frames in (pageable, one array per frame, as Dataset hands them out), filled FrameResults out.  Never
+    `value`.  Each loop runs once to warm its context (workspace allocation, first launches) and is timed on its second run over the
+    same Processor.  Frame synthesis is excluded (8 distinct pairs, generated before any clock starts)."""
+    import logging
+    import numpy as np
+    from mavflow.processor import Processor, SyntheticDataset
+    from mavflow.run_config import RunConfig
+
+    def make(N, use_fb=True):
+        ds = SyntheticDataset(W, H, N, use_farneback=use_fb, distinct=8, dangle=(0.004, -0.002, 0.001))
+        for i in range(8):
+            ds._pair(i); ds.get_gt_of(i)
+        for _ in range(N):
+            ds.get_frame()
+        ds.get_segmentation(0); ds.get_sky_segmentation(0); ds.get_depth(0)
+        cfg = RunConfig(logging.getLogger("bench"), ds, "", False, False, False, True, False, False, "FLOW_FOE_CLUSTERING")
+        return Processor(cfg), ds
+
+    def timed(p, ds, fn, N):
+        ds.N = min(N, batch + 1)
+        fn()                                               # warm: context, workspace, pipeline slots
+        p.frame_index = 0; p.detection_results = {}; p.config.results = {}
+        ds.N = N
+        np.random.seed(7)
+        t0 = time.perf_counter()
+        res = fn()
+        dt = time.perf_counter() - t0
+        assert len(res) == N - 1 and all(r.tpr is not None for r in res.values())
+        return dt, res
+
+    out = {"workload": f"{W}x{H} SyntheticDataset (8 distinct pairs cycled, pageable numpy frames), Processor loops of mavflow.processor; "
+                       f"second run of each loop timed, frame synthesis excluded"}
+    N = batch * n_batches + 1
+    p, ds = make(N)
+    dt, res_b = timed(p, ds, lambda: p.run_detection_batched(batch=batch), N)
+    out["run_detection_batched"] = {"batch": batch, "pairs": N - 1, "pairs_per_s": round((N - 1) / dt, 1), "ms_per_pair": round(1e3 * dt / (N - 1), 4)}
+    p.release()
+    N1 = n_unbatched + 1
+    p, ds = make(N1)
+    dt, res_1 = timed(p, ds, p.run_detection, N1)
+    out["run_detection"] = {"flow_seam": "Farneback on the GPU (DeviceArray)", "frames": N1 - 1, "ms_per_frame": round(1e3 * dt / (N1 - 1), 4),
+                            "pairs_per_s": round((N1 - 1) / dt, 1)}
+    same = all(vars(res_1[i]) == vars(res_b[i]) for i in range(min(N1, N) - 1))
+    out["batched_and_unbatched_results_identical"] = bool(same)
+    p.release()
+    p, ds = make(N1, use_fb=False)
+    dt, _ = timed(p, ds, p.run_detection, N1)
+    out["run_detection_host_flow"] = {"flow_seam": "float32 host array per frame (what a .flo file gives)", "frames": N1 - 1,
+                                      "ms_per_frame": round(1e3 * dt / (N1 - 1), 4)}
+    p.release()
+    if staged:
+        Ns = 13
+        p, ds = make(Ns)
+        dt, _ = timed(p, ds, p.run_detection_staged, Ns)
+        out["run_detection_staged"] = {"frames": Ns - 1, "ms_per_frame": round(1e3 * dt / (Ns - 1), 4)}
+        p.release()
+    return out
+
+
 def measured_ceilings(ctx):
     """What this GPU delivers to a plain streaming kernel with the sweeps' 3 reads : 1 write mix (float4 per thread, grid-stride),
     measured now, in this process (mav_membw_probe): once with a footprint the 256 MB Infinity Cache holds, once far beyond it."""

@@ -112,6 +112,7 @@ int mav_device_count(void);       /* <= 0 when no GPU is visible */
  *   "strip"            width in tiles of the column strips of the XCD-aware tile order (0 = automatic)
  *   "phi_screen"       0: every pixel of the phi / threshold stage takes the exact path (default 1: float32 screen in front of it)
  *   "phi_yloop"        16-row blocks per workgroup of the phi kernel (0 = automatic)
+ *   "upload_threads"   host threads that stage pageable sources for mav_upload_gather (default 4, the caller included; until its first call)
  * None of them changes a result bit (tests/test_gpu_flow.py, tests/test_gpu_screen.py). */
 int mav_set_option(mav_ctx*, const char* name, long value);
 int mav_get_option(mav_ctx*, const char* name, long* value);
@@ -219,6 +220,13 @@ int mav_detect_dev(mav_ctx*, const float* flow, const uint32_t* samples, const d
  * (the caller's buffer, or the context's own workspace when the caller passed flow == NULL); NULL before the first call.
  * Lets a caller that keeps the flow in the workspace (bench.py) still inspect it. */
 const float* mav_last_flow_dev(const mav_ctx*);
+/* im_helpers.calculate_tpr_fpr [src/im_helpers.py:244-252, called at src/processor.py:350-351] for device-resident masks against a
+ * device-resident ground truth, counts left on the device (4 x int64 per pair: positives, negatives, true / false positives): the
+ * validation tail of a batch as one more launch behind mav_process_batch_dev / mav_detect_dev.  gt_images = batch: one ground-truth
+ * image per pair; gt_images = 1: ONE image shared by every pair (a sequence whose segmentation does not change).  Either mask (with
+ * its counts buffer) may be NULL; both masks share one pass over the ground truth. */
+int mav_tpr_fpr_counts_dev(mav_ctx*, const uint8_t* gt, int gt_images, const uint8_t* mask_fixed, const uint8_t* mask_dyn, int mask_value,
+                           int batch, int64_t* counts_fixed, int64_t* counts_dyn);
 int mav_sync(mav_ctx*);
 void* mav_stream(mav_ctx*); /* the context's hipStream_t */
 
@@ -241,6 +249,26 @@ int mav_upload_async(mav_ctx*, void* dst_dev, const void* src_host, size_t bytes
  * overlap is gone; this form overlaps in either order.  Overwriting a buffer that enqueued work still reads is the caller's bug. */
 int mav_upload_async_unordered(mav_ctx*, void* dst_dev, const void* src_host, size_t bytes);
 int mav_upload_fence(mav_ctx*);
+/* GATHER upload: `count` separate host arrays of bytes_each bytes -> one contiguous device buffer (array i at dst_dev + i * bytes_each),
+ * on the copy stream.  This is the shape the reference's loop hands its data over in: one numpy array per frame from
+ * Dataset.get_frame / get_flow_uv [src/datasets/dataset.py:205-230], i.e. 128 separate 2 MB arrays for a batch of 64 pairs at 1080p.
+ * Pageable sources are copied into a ring of page-locked chunks by a few worker threads (option "upload_threads", default 4: the
+ * calling thread plus three; settable until the first call) and every chunk crosses PCIe while the next one is being filled;
+ * sources that are page-locked already (mav_host_alloc) are sent from where they are.  On return every source has been READ (the
+ * caller may overwrite it); the transfers themselves complete on the copy stream -- mav_upload_fence orders the compute stream
+ * behind them.  ordered != 0: as mav_upload_async, the copies wait for everything enqueued on the compute stream so far;
+ * ordered == 0: as mav_upload_async_unordered.  The same pointer may appear more than once (replication). */
+int mav_upload_gather(mav_ctx*, void* dst_dev, const void* const* src_host, int count, size_t bytes_each, int ordered);
+/* Device -> host copy enqueued on the context's stream (dst_host should be page-locked: mav_host_alloc); complete after mav_sync or
+ * after a marker recorded behind it. */
+int mav_download_async(mav_ctx*, void* dst_host, const void* src_dev, size_t bytes);
+/* Markers: "everything enqueued on the context's stream so far" as an object the host can wait for WITHOUT draining the stream
+ * (mav_sync also waits for whatever was enqueued after the marker).  A loop that keeps two batches in flight records one per batch
+ * behind the batch's result download and waits for it when it needs those results. */
+int mav_marker_create(mav_ctx*, void** marker_out);
+int mav_marker_record(mav_ctx*, void* marker);
+int mav_marker_wait(mav_ctx*, void* marker);
+int mav_marker_destroy(mav_ctx* /* may be NULL */, void* marker);
 
 /* HIP-event timing on the context's stream (bench.py): start/stop bracket enqueued work; stop synchronises. */
 int mav_timer_start(mav_ctx*);

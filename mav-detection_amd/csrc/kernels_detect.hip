@@ -694,33 +694,78 @@ void launch_window_max(hipStream_t st, const uint8_t* img, int B, int W, int H, 
 }
 
 // calculate_tpr_fpr counts for gt (u8) against mask_value * mask: the reference's products in wide integers (no u8 wrap).
-__global__ __launch_bounds__(256) void k_tpr_fpr(const uint8_t* __restrict__ gt, const uint8_t* __restrict__ mask, unsigned mask_value, size_t npx,
-                                                 unsigned long long* __restrict__ counts)
+// One pass over the ground truth serves one mask or two (the fixed and the dynamic mask of a detection call); gt_stride = 0: one
+// ground-truth image for every pair of the batch (a constant segmentation).  16 bytes per thread and load where the images are
+// 16-byte addressable, byte by byte otherwise; the counts are integers, so the order of the additions is immaterial.
+__device__ __forceinline__ void tpr_fpr_byte(unsigned gv, unsigned m0, unsigned m1, unsigned mask_value, unsigned& pos, unsigned& neg, unsigned& tp0,
+                                             unsigned& fp0, unsigned& tp1, unsigned& fp1)
+{
+    const unsigned v0 = m0 ? mask_value : 0u, v1 = m1 ? mask_value : 0u;
+    pos += gv > 127u;
+    neg += (255u - gv) > 127u;
+    tp0 += (gv * v0) > 127u;
+    fp0 += ((255u - gv) * v0) > 127u;
+    tp1 += (gv * v1) > 127u;
+    fp1 += ((255u - gv) * v1) > 127u;
+}
+template <bool TWO, bool VEC>
+__global__ __launch_bounds__(256) void k_tpr_fpr(const uint8_t* __restrict__ gt, size_t gt_stride, const uint8_t* __restrict__ mask0,
+                                                 const uint8_t* __restrict__ mask1, unsigned mask_value, size_t npx,
+                                                 unsigned long long* __restrict__ counts0, unsigned long long* __restrict__ counts1)
 {
     const int b = blockIdx.y;
-    const uint8_t* g = gt + b * npx;
-    const uint8_t* m = mask + b * npx;
-    unsigned pos = 0, neg = 0, tp = 0, fp = 0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npx; i += (size_t)gridDim.x * 256) {
-        const unsigned gv = g[i], mv = m[i] ? mask_value : 0u;
-        pos += gv > 127u;
-        neg += (255u - gv) > 127u;
-        tp += (gv * mv) > 127u;
-        fp += ((255u - gv) * mv) > 127u;
+    const uint8_t* g = gt + b * gt_stride;
+    const uint8_t* m0 = mask0 + b * npx;
+    const uint8_t* m1 = TWO ? mask1 + b * npx : m0;
+    unsigned pos = 0, neg = 0, tp0 = 0, fp0 = 0, tp1 = 0, fp1 = 0;
+    if (VEC) {
+        const size_t nv = npx / 16;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
+            const uint4 gv = ((const uint4*)g)[i], a = ((const uint4*)m0)[i], c = TWO ? ((const uint4*)m1)[i] : a;
+            const unsigned gw[4] = {gv.x, gv.y, gv.z, gv.w}, aw[4] = {a.x, a.y, a.z, a.w}, cw[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+            for (int w = 0; w < 4; w++)
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    tpr_fpr_byte((gw[w] >> (8 * k)) & 255u, (aw[w] >> (8 * k)) & 255u, (cw[w] >> (8 * k)) & 255u, mask_value, pos, neg, tp0, fp0, tp1, fp1);
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npx; i += (size_t)gridDim.x * 256)
+            tpr_fpr_byte(g[i], m0[i], TWO ? m1[i] : 0u, mask_value, pos, neg, tp0, fp0, tp1, fp1);
     }
     for (int o = 32; o > 0; o >>= 1) {
-        pos += __shfl_xor(pos, o); neg += __shfl_xor(neg, o); tp += __shfl_xor(tp, o); fp += __shfl_xor(fp, o);
+        pos += __shfl_xor(pos, o); neg += __shfl_xor(neg, o); tp0 += __shfl_xor(tp0, o); fp0 += __shfl_xor(fp0, o);
+        if (TWO) { tp1 += __shfl_xor(tp1, o); fp1 += __shfl_xor(fp1, o); }
     }
     if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&counts[4 * b], (unsigned long long)pos); atomicAdd(&counts[4 * b + 1], (unsigned long long)neg);
-        atomicAdd(&counts[4 * b + 2], (unsigned long long)tp); atomicAdd(&counts[4 * b + 3], (unsigned long long)fp);
+        atomicAdd(&counts0[4 * b], (unsigned long long)pos); atomicAdd(&counts0[4 * b + 1], (unsigned long long)neg);
+        atomicAdd(&counts0[4 * b + 2], (unsigned long long)tp0); atomicAdd(&counts0[4 * b + 3], (unsigned long long)fp0);
+        if (TWO) {
+            atomicAdd(&counts1[4 * b], (unsigned long long)pos); atomicAdd(&counts1[4 * b + 1], (unsigned long long)neg);
+            atomicAdd(&counts1[4 * b + 2], (unsigned long long)tp1); atomicAdd(&counts1[4 * b + 3], (unsigned long long)fp1);
+        }
+    }
+}
+void launch_tpr_fpr2(hipStream_t st, const uint8_t* gt, size_t gt_stride, const uint8_t* mask0, const uint8_t* mask1, unsigned mask_value, int B,
+                     int W, int H, unsigned long long* counts0, unsigned long long* counts1)
+{
+    const size_t npx = (size_t)W * H;
+    hipMemsetAsync(counts0, 0, sizeof(unsigned long long) * 4 * B, st);
+    if (mask1) hipMemsetAsync(counts1, 0, sizeof(unsigned long long) * 4 * B, st);
+    const bool vec = npx % 16 == 0 && gt_stride % 16 == 0 && (((uintptr_t)gt | (uintptr_t)mask0 | (uintptr_t)mask1) & 15) == 0;
+    const dim3 grid(128, B), blk(256);
+    if (mask1) {
+        if (vec) hipLaunchKernelGGL((k_tpr_fpr<true, true>), grid, blk, 0, st, gt, gt_stride, mask0, mask1, mask_value, npx, counts0, counts1);
+        else hipLaunchKernelGGL((k_tpr_fpr<true, false>), grid, blk, 0, st, gt, gt_stride, mask0, mask1, mask_value, npx, counts0, counts1);
+    } else {
+        if (vec) hipLaunchKernelGGL((k_tpr_fpr<false, true>), grid, blk, 0, st, gt, gt_stride, mask0, mask1, mask_value, npx, counts0, counts1);
+        else hipLaunchKernelGGL((k_tpr_fpr<false, false>), grid, blk, 0, st, gt, gt_stride, mask0, mask1, mask_value, npx, counts0, counts1);
     }
 }
 void launch_tpr_fpr(hipStream_t st, const uint8_t* gt, const uint8_t* mask, unsigned mask_value, int B, int W, int H,
                     unsigned long long* counts)
 {
-    hipMemsetAsync(counts, 0, sizeof(unsigned long long) * 4 * B, st);
-    hipLaunchKernelGGL(k_tpr_fpr, dim3(128, B), dim3(256), 0, st, gt, mask, mask_value, (size_t)W * H, counts);
+    launch_tpr_fpr2(st, gt, (size_t)W * H, mask, nullptr, mask_value, B, W, H, counts, nullptr);
 }
 
 // cv2.cvtColor(COLOR_BGR2GRAY) on u8 (farneback.py:21,74): fixed point, (B*1868 + G*9617 + R*4899 + 8192) >> 14  (SURVEY A.7).

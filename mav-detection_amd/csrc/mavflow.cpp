@@ -8,8 +8,12 @@
 #include <stdio.h>
 #include <string.h>
 
-#include <string>
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "mavflow_internal.h"
@@ -193,6 +197,79 @@ struct Layer {
     int* coord = nullptr;    // device: xs[w] | xf[w] | ys[h] | yf[h] -- the resize coordinates of the layer's columns and rows (coarse layers)
 };
 
+// ---- gather uploads: many host arrays -> one contiguous device buffer ----------------------------------------------------------
+// The reference's loop is handed one numpy array per frame (Dataset.get_frame / get_flow_uv, src/datasets/dataset.py:205-230); a batch
+// of 64 pairs is 128 separate pageable 2 MB arrays.  hipMemcpy from pageable memory stages through the runtime's own bounce buffer on
+// the calling thread (~6 GB/s here); np.stack + one copy touches every byte twice.  The stager copies the sources into a ring of
+// page-locked chunks on a few worker threads (memcpy at DRAM rate) and issues one H2D per chunk on the copy stream while the next
+// chunk is being filled, so the PCIe transfer hides behind the staging.  A source that is already page-locked (mav_host_alloc, the
+// Python layer's pinned pool) is copied straight from where it is.
+struct Stager {
+    enum { NCHUNK = 4 };
+    static constexpr size_t CHUNK = (size_t)16 << 20, PIECE = (size_t)512 << 10;
+    struct Seg { char* dst; const char* src; size_t n; };
+    void* chunk[NCHUNK] = {nullptr};
+    hipEvent_t sent[NCHUNK] = {nullptr};
+    bool in_flight[NCHUNK] = {false};
+    unsigned next_chunk = 0;
+    std::vector<std::thread> workers;
+    std::mutex m;
+    std::condition_variable cv_job, cv_done;
+    std::vector<Seg> segs;
+    std::atomic<size_t> next_seg{0};
+    unsigned long long generation = 0;
+    int busy = 0;
+    bool stop = false;
+
+    void run_segments()
+    {
+        for (;;) {
+            const size_t i = next_seg.fetch_add(1);
+            if (i >= segs.size()) return;
+            memcpy(segs[i].dst, segs[i].src, segs[i].n);
+        }
+    }
+    void worker()
+    {
+        unsigned long long seen = 0;
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv_job.wait(lk, [&] { return stop || generation != seen; });
+            if (stop) return;
+            seen = generation;
+            lk.unlock();
+            run_segments();
+            lk.lock();
+            if (--busy == 0) cv_done.notify_one();
+        }
+    }
+    // copy every segment of `segs` (the calling thread takes part), return when all are done
+    void copy_all()
+    {
+        next_seg.store(0);
+        if (workers.empty() || segs.size() < 2) { run_segments(); return; }
+        {
+            std::lock_guard<std::mutex> lk(m);
+            busy = (int)workers.size();
+            generation++;
+        }
+        cv_job.notify_all();
+        run_segments();
+        std::unique_lock<std::mutex> lk(m);
+        cv_done.wait(lk, [&] { return busy == 0; });
+    }
+    void shutdown()
+    {
+        { std::lock_guard<std::mutex> lk(m); stop = true; }
+        cv_job.notify_all();
+        for (auto& t : workers) t.join();
+        workers.clear();
+        for (int i = 0; i < NCHUNK; i++) {
+            if (sent[i]) { hipEventSynchronize(sent[i]); hipEventDestroy(sent[i]); }
+            if (chunk[i]) hipHostFree(chunk[i]);
+        }
+    }
+};
 enum KernelId { K_BLUR_RESIZE, K_POLYEXP, K_UPDATE, K_ITER, K_ITER_COARSE, K_FOE, K_PHI, K_MISC, K_COUNT };
 static const char* const kKernelNames[K_COUNT] = {"blur_resize", "polyexp", "update_matrices", "blur_iter", "blur_iter_coarse",
                                                   "foe_ransac", "phi_mask_box", "misc"};
@@ -205,6 +282,8 @@ struct mav_ctx {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;   // uploads that overlap the compute stream (mav_upload_async / mav_upload_fence)
     hipEvent_t copy_done = nullptr, compute_mark = nullptr;
+    struct Stager* stager = nullptr;     // mav_upload_gather: page-locked ring + worker threads (created by its first call)
+    int upload_threads = 4;              // option "upload_threads"
     const float* last_flow = nullptr;    // where the latest farneback / process_batch call wrote its flow (mav_last_flow_dev)
     const uint8_t *last_mf = nullptr, *last_md = nullptr;   // masks of the latest host-pointer detection call, still in their
     int last_mask_batch = 0;                                // staging blocks (mav_last_masks_tpr_fpr)
@@ -268,14 +347,14 @@ struct mav_ctx {
     size_t htmp_stride = 0;
     bool ws_ready = false;         // the Farneback workspace exists (ensure_workspace: allocated by the first call that computes flow)
     size_t ws_bytes = 0;           // its size
-    size_t deep_bytes = 0;
+    size_t group_bytes = 0, deep_bytes = 0;   // ws_bytes = the group slots + the deep set (0 until a call of more than one group)
     float* flow_ws = nullptr;      // lazily allocated (max_batch) when the caller does not want the flow
     // detection scratch (max_batch)
     FoeScratch foe_sc{nullptr, nullptr, nullptr};
     int foe_sc_n = 0;
     double* foe_dev = nullptr;
     int32_t* box_acc = nullptr;
-    unsigned long long* u64_scratch = nullptr;  // [max_batch*4]
+    unsigned long long* u64_scratch = nullptr;  // [max_batch*8]
     int* i32_scratch = nullptr;                 // [max_batch]
     DerotParams* derot_dev = nullptr;
     // staging buffers of the host-pointer entry points: slot i of a call re-uses the block slot i of the previous call
@@ -373,30 +452,38 @@ static int alloc_group(mav_ctx* c, int group)
         }
         total += sizeof(float) * elems[i];
     }
-    // the deep layers' work set does not depend on the group: allocated with the first workspace, kept across "group" changes
-    if (c->kd > 0 && !c->deep.I) {
-        const size_t D = (size_t)c->deep_cap, dt = c->c_total - c->c_off[c->kd], top = c->c_stride[c->kd];
-        const size_t de[6] = {2 * D * dt, 10 * D * dt, 5 * D * top, 5 * D * top, 2 * D * top, 2 * D * top};
-        float* d[6] = {nullptr};
-        for (int i = 0; i < 6; i++) {
-            const hipError_t e = hipMalloc(&d[i], sizeof(float) * de[i]);
-            if (e != hipSuccess) {
-                for (int j = 0; j < 6; j++) if (d[j]) hipFree(d[j]);
-                for (int j = 0; j < NB; j++) if (fresh[j]) hipFree(fresh[j]);
-                (void)hipGetLastError();
-                return fail(e == hipErrorOutOfMemory ? MAV_ERR_OOM : MAV_ERR_HIP, "deep-layer workspace (%zu bytes): %s", sizeof(float) * de[i], hipGetErrorString(e));
-            }
-            c->deep_bytes += sizeof(float) * de[i];
-        }
-        c->deep.I = d[0]; c->deep.R = d[1]; c->deep.Ma = d[2]; c->deep.Mb = d[3]; c->deep.f[0] = d[4]; c->deep.f[1] = d[5];
-    }
     mav_ctx::WorkSet& w = c->ws;
     float** bufs[NB] = {&w.I, &w.R, &w.Ma, &w.Mb, &w.fc[0], &w.fc[1], &w.Htmp, &w.Ic, &w.Rc};
     for (int i = 0; i < NB; i++) { if (*bufs[i]) hipFree(*bufs[i]); *bufs[i] = fresh[i]; }
     c->group = group;
     c->small_g = (int)sg;
     c->ws_ready = true;
-    c->ws_bytes = total + c->deep_bytes;
+    c->group_bytes = total;
+    c->ws_bytes = c->group_bytes + c->deep_bytes;
+    return MAV_OK;
+}
+// The deep layers' work set (deep_layers) does not depend on the group and is reachable only by calls of more than one group
+// (use_deep_batch): allocated by the first such call -- a context whose calls never exceed one group (max_batch <= group, or one-pair
+// calls) never holds it (150 MB per pair at 3840x2160 / 5 levels) --, kept across "group" changes until mav_destroy.
+static int ensure_deep(mav_ctx* c)
+{
+    if (c->kd <= 0 || c->deep.I) return MAV_OK;
+    const size_t D = (size_t)c->deep_cap, dt = c->c_total - c->c_off[c->kd], top = c->c_stride[c->kd];
+    const size_t de[6] = {2 * D * dt, 10 * D * dt, 5 * D * top, 5 * D * top, 2 * D * top, 2 * D * top};
+    float* d[6] = {nullptr};
+    size_t bytes = 0;
+    for (int i = 0; i < 6; i++) {
+        const hipError_t e = hipMalloc(&d[i], sizeof(float) * de[i]);
+        if (e != hipSuccess) {
+            for (int j = 0; j < 6; j++) if (d[j]) hipFree(d[j]);
+            (void)hipGetLastError();
+            return fail(e == hipErrorOutOfMemory ? MAV_ERR_OOM : MAV_ERR_HIP, "deep-layer workspace (%zu bytes): %s", sizeof(float) * de[i], hipGetErrorString(e));
+        }
+        bytes += sizeof(float) * de[i];
+    }
+    c->deep.I = d[0]; c->deep.R = d[1]; c->deep.Ma = d[2]; c->deep.Mb = d[3]; c->deep.f[0] = d[4]; c->deep.f[1] = d[5];
+    c->deep_bytes = bytes;                     // only once the whole set exists
+    c->ws_bytes = c->group_bytes + c->deep_bytes;
     return MAV_OK;
 }
 // The Farneback workspace (174 MB per 1080p slot, 16 slots by default) belongs to the calls that compute flow: a context created for
@@ -419,6 +506,8 @@ extern "C" int mav_destroy(mav_ctx* c)
     if (!c) return MAV_OK;
     hipSetDevice(c->device);
     (void)sync_all_streams(c);
+    if (c->copy_stream) hipStreamSynchronize(c->copy_stream);
+    if (c->stager) { c->stager->shutdown(); delete c->stager; c->stager = nullptr; }
     for (auto& l : c->layers) free_layer(l);
     {
         mav_ctx::WorkSet& w = c->ws;
@@ -539,7 +628,7 @@ extern "C" int mav_create(mav_ctx** out, int device, int W, int H, int max_batch
     const size_t B = (size_t)max_batch;
     HIPB(hipMalloc(&c->foe_dev, sizeof(double) * 2 * B));
     HIPB(hipMalloc(&c->box_acc, sizeof(int32_t) * 4 * B));
-    HIPB(hipMalloc(&c->u64_scratch, sizeof(unsigned long long) * 4 * B));
+    HIPB(hipMalloc(&c->u64_scratch, sizeof(unsigned long long) * 8 * B));   // two count blocks of 4 per pair
     HIPB(hipMalloc(&c->i32_scratch, sizeof(int) * B));
     HIPB(hipMalloc(&c->derot_dev, sizeof(DerotParams) * B));
     HIPB(hipMalloc(&c->foe_sc.count, sizeof(int) * B));
@@ -574,6 +663,7 @@ static long* option_slot(mav_ctx* c, const char* name, long* tmp)
 extern "C" int mav_get_option(mav_ctx* c, const char* name, long* value)
 {
     if (!c || !name || !value) return fail(MAV_ERR_ARG, "mav_get_option: NULL argument");
+    if (!strcmp(name, "upload_threads")) { *value = c->upload_threads; return MAV_OK; }
     long tmp;
     if (!option_slot(c, name, &tmp)) return fail(MAV_ERR_ARG, "unknown option '%s'", name);
     *value = tmp;
@@ -582,6 +672,12 @@ extern "C" int mav_get_option(mav_ctx* c, const char* name, long* value)
 extern "C" int mav_set_option(mav_ctx* c, const char* name, long value)
 {
     if (!c || !name) return fail(MAV_ERR_ARG, "mav_set_option: NULL argument");
+    if (!strcmp(name, "upload_threads")) {      // host side of mav_upload_gather; not part of the launch schedule (mav_schedule_info)
+        if (value < 1 || value > 64) return fail(MAV_ERR_ARG, "option 'upload_threads' must be in [1, 64], got %ld", value);
+        if (c->stager) return fail(MAV_ERR_STATE, "upload_threads must be set before the first mav_upload_gather call");
+        c->upload_threads = (int)value;
+        return MAV_OK;
+    }
     const OptionDesc* d = nullptr;
     for (const auto& o : kOptions) if (!strcmp(o.name, name)) d = &o;
     if (!d) return fail(MAV_ERR_ARG, "unknown option '%s'", name);
@@ -649,7 +745,7 @@ extern "C" int mav_mem_info(mav_ctx* c, size_t* dev_free, size_t* dev_total, siz
         if (c->flow_ws) n += sizeof(float) * 2 * c->n0 * B;
         if (c->sat) n += sizeof(unsigned long long) * (size_t)(c->W + 1) * (c->H + 1) * B;
         if (c->foe_sc.cand) n += sizeof(double) * 2 * (size_t)c->foe_sc_n * B;
-        n += B * (sizeof(double) * 2 + sizeof(int32_t) * 4 + sizeof(unsigned long long) * 4 + sizeof(int) + sizeof(DerotParams) + sizeof(int) +
+        n += B * (sizeof(double) * 2 + sizeof(int32_t) * 4 + sizeof(unsigned long long) * 8 + sizeof(int) + sizeof(DerotParams) + sizeof(int) +
                   sizeof(unsigned long long) + sizeof(unsigned) * 2);
         for (const auto& l : c->layers) n += sizeof(float) * l.ksize + (l.coord ? sizeof(int) * 2 * (size_t)(l.w + l.h) : 0);
         for (const auto& b : c->scratch) n += b.cap;
@@ -731,6 +827,128 @@ extern "C" int mav_upload_fence(mav_ctx* c)
     if (!c) return fail(MAV_ERR_ARG, "mav_upload_fence: NULL context");
     HIPCHK(hipEventRecord(c->copy_done, c->copy_stream));
     HIPCHK(hipStreamWaitEvent(c->stream, c->copy_done, 0));   // work enqueued after this call sees the uploaded bytes
+    return MAV_OK;
+}
+
+static int ensure_stager(mav_ctx* c)
+{
+    if (c->stager) return MAV_OK;
+    Stager* s = new Stager();
+    for (int i = 0; i < Stager::NCHUNK; i++) {
+        if (hipHostMalloc(&s->chunk[i], Stager::CHUNK, hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&s->sent[i], hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            s->shutdown();
+            delete s;
+            return fail(MAV_ERR_OOM, "page-locked staging ring (%d x %zu bytes)", (int)Stager::NCHUNK, (size_t)Stager::CHUNK);
+        }
+    }
+    for (int t = 1; t < c->upload_threads; t++) s->workers.emplace_back([s] { s->worker(); });   // the calling thread is the first copier
+    c->stager = s;
+    return MAV_OK;
+}
+static bool host_ptr_is_page_locked(const void* p)
+{
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof(a));
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // plain malloc'd memory: an error or "unregistered"
+    return a.type == hipMemoryTypeHost;
+}
+
+extern "C" int mav_upload_gather(mav_ctx* c, void* dst_dev, const void* const* src_host, int count, size_t bytes_each, int ordered)
+{
+    if (!c || !dst_dev || !src_host || count < 1) return fail(MAV_ERR_ARG, "mav_upload_gather: NULL argument or count < 1");
+    for (int i = 0; i < count; i++) if (!src_host[i]) return fail(MAV_ERR_ARG, "mav_upload_gather: source %d is NULL", i);
+    if (!bytes_each) return MAV_OK;
+    HIPCHK(hipSetDevice(c->device));
+    if (ordered) {               // as mav_upload_async: behind everything enqueued on the compute stream so far
+        HIPCHK(hipEventRecord(c->compute_mark, c->stream));
+        HIPCHK(hipStreamWaitEvent(c->copy_stream, c->compute_mark, 0));
+    }
+    char* dst = (char*)dst_dev;
+    Stager* s = nullptr;
+    size_t fill = 0;                           // bytes staged in the chunk being filled
+    size_t chunk_dst = 0;                      // device offset the chunk being filled starts at
+    auto flush = [&]() -> int {                // copy the collected segments, send the chunk
+        if (!fill) return MAV_OK;
+        const unsigned k = s->next_chunk % Stager::NCHUNK;
+        s->copy_all();
+        s->segs.clear();
+        HIPCHK(hipMemcpyAsync(dst + chunk_dst, s->chunk[k], fill, hipMemcpyHostToDevice, c->copy_stream));
+        HIPCHK(hipEventRecord(s->sent[k], c->copy_stream));
+        s->in_flight[k] = true;
+        s->next_chunk++;
+        fill = 0;
+        return MAV_OK;
+    };
+    auto open_chunk = [&](size_t dev_off) -> int {   // the next ring slot, once its previous transfer has left it
+        const unsigned k = s->next_chunk % Stager::NCHUNK;
+        if (s->in_flight[k]) { HIPCHK(hipEventSynchronize(s->sent[k])); s->in_flight[k] = false; }
+        chunk_dst = dev_off;
+        return MAV_OK;
+    };
+    for (int i = 0; i < count; i++) {
+        const char* src = (const char*)src_host[i];
+        const size_t dev_off = (size_t)i * bytes_each;
+        if (host_ptr_is_page_locked(src)) {    // straight from where it is; whatever was staged before it goes first (keeps nothing waiting)
+            if (s) CHK(flush());
+            HIPCHK(hipMemcpyAsync(dst + dev_off, src, bytes_each, hipMemcpyHostToDevice, c->copy_stream));
+            continue;
+        }
+        if (!s) { CHK(ensure_stager(c)); s = c->stager; }
+        size_t done = 0;
+        while (done < bytes_each) {
+            if (!fill) CHK(open_chunk(dev_off + done));
+            const size_t n = std::min(bytes_each - done, Stager::CHUNK - fill);
+            char* into = (char*)s->chunk[s->next_chunk % Stager::NCHUNK] + fill;
+            for (size_t o = 0; o < n; o += Stager::PIECE)
+                s->segs.push_back({into + o, src + done + o, std::min(Stager::PIECE, n - o)});
+            fill += n; done += n;
+            if (fill == Stager::CHUNK) CHK(flush());
+        }
+    }
+    if (s) {
+        CHK(flush());
+        // the sources have been read; the ring's last transfers may still be in flight (the next call waits for a slot before it refills it)
+    }
+    return MAV_OK;
+}
+
+extern "C" int mav_download_async(mav_ctx* c, void* dst_host, const void* src_dev, size_t bytes)
+{
+    if (!c || !dst_host || !src_dev) return fail(MAV_ERR_ARG, "mav_download_async: NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    return MAV_OK;
+}
+
+// Markers: "everything enqueued on the context's stream so far" as an object the host can wait for without draining the stream
+// (mav_sync waits for the work enqueued AFTER the marker too).  The pipelined loop records one per batch.
+extern "C" int mav_marker_create(mav_ctx* c, void** out)
+{
+    if (!c || !out) return fail(MAV_ERR_ARG, "mav_marker_create: NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    hipEvent_t e = nullptr;
+    HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *out = (void*)e;
+    return MAV_OK;
+}
+extern "C" int mav_marker_record(mav_ctx* c, void* marker)
+{
+    if (!c || !marker) return fail(MAV_ERR_ARG, "mav_marker_record: NULL argument");
+    HIPCHK(hipEventRecord((hipEvent_t)marker, c->stream));
+    return MAV_OK;
+}
+extern "C" int mav_marker_wait(mav_ctx* c, void* marker)
+{
+    if (!c || !marker) return fail(MAV_ERR_ARG, "mav_marker_wait: NULL argument");
+    HIPCHK(hipEventSynchronize((hipEvent_t)marker));
+    return MAV_OK;
+}
+extern "C" int mav_marker_destroy(mav_ctx* c, void* marker)
+{
+    (void)c;
+    if (marker) HIPCHK(hipEventDestroy((hipEvent_t)marker));
     return MAV_OK;
 }
 
@@ -1285,6 +1503,7 @@ extern "C" int mav_farneback_dev(mav_ctx* c, const uint8_t* prev, const uint8_t*
     // frame: the flow is bit-identical to the two-batch form; tests/test_gpu_flow.py).  Option "share_frames" = 0 switches it off.
     const bool seq = c->share_frames && next == prev + c->n0;
     const bool deep = use_deep_batch(c, batch);
+    if (deep) CHK(ensure_deep(c));
     const int chunk = deep ? c->deep_cap : batch;
     for (int d0 = 0; d0 < batch; d0 += chunk) {
         const int D = batch - d0 < chunk ? batch - d0 : chunk;
@@ -1884,15 +2103,37 @@ extern "C" int mav_last_masks_tpr_fpr(mav_ctx* c, const uint8_t* gt, int mask_va
     DevBuf dg;
     CHK(dg.upload(c, gt, c->n0 * batch));
     c->scratch_next = mark;          // the call is synchronous: its block is free again on return, a repeated call re-uses it
-    for (int k = 0; k < 2; k++) {
-        int64_t* out = k == 0 ? counts_fixed : counts_dyn;
-        if (!out) continue;
-        launch_tpr_fpr(c->stream, dg.as<uint8_t>(), k == 0 ? mf : md, (unsigned)mask_value, batch, c->W, c->H, c->u64_scratch);
-        CHK(check_launch("tpr_fpr"));
-        CHK(download(c, out, c->u64_scratch, sizeof(int64_t) * 4 * batch));
-        CHK(mav_sync(c));            // u64_scratch is reused by the second pass
-    }
-    return MAV_OK;
+    // one pass over the ground truth for both masks
+    unsigned long long *c0 = c->u64_scratch, *c1 = c->u64_scratch + 4 * (size_t)batch;
+    const uint8_t* m0 = counts_fixed ? mf : md;
+    const uint8_t* m1 = (counts_fixed && counts_dyn) ? md : nullptr;
+    if (!counts_fixed && !counts_dyn) return MAV_OK;
+    launch_tpr_fpr2(c->stream, dg.as<uint8_t>(), c->n0, m0, m1, (unsigned)mask_value, batch, c->W, c->H, c0, m1 ? c1 : nullptr);
+    CHK(check_launch("tpr_fpr"));
+    CHK(download(c, counts_fixed ? counts_fixed : counts_dyn, c0, sizeof(int64_t) * 4 * batch));
+    if (m1) CHK(download(c, counts_dyn, c1, sizeof(int64_t) * 4 * batch));
+    return mav_sync(c);
+}
+
+// calculate_tpr_fpr of one or two device-resident masks against a device-resident ground truth, counts left on the device: the
+// validation tail of a batch [src/processor.py:350-351] as two more launches behind mav_process_batch_dev, no transfer, no sync.
+extern "C" int mav_tpr_fpr_counts_dev(mav_ctx* c, const uint8_t* gt, int gt_images, const uint8_t* mask_fixed, const uint8_t* mask_dyn,
+                                      int mask_value, int batch, int64_t* counts_fixed, int64_t* counts_dyn)
+{
+    if (!c || !gt) return fail(MAV_ERR_ARG, "mav_tpr_fpr_counts_dev: NULL argument");
+    if (batch < 1 || batch > c->max_batch) return fail(MAV_ERR_ARG, "batch %d outside [1, %d]", batch, c->max_batch);
+    if (gt_images != 1 && gt_images != batch) return fail(MAV_ERR_ARG, "mav_tpr_fpr_counts_dev: gt_images must be 1 (shared) or batch (%d), got %d", batch, gt_images);
+    if (mask_value < 1 || mask_value > 65535) return fail(MAV_ERR_ARG, "mav_tpr_fpr_counts_dev: mask_value %d outside [1, 65535]", mask_value);
+    if ((mask_fixed && !counts_fixed) || (mask_dyn && !counts_dyn) || (!mask_fixed && !mask_dyn))
+        return fail(MAV_ERR_ARG, "mav_tpr_fpr_counts_dev: every mask needs its counts buffer, and at least one mask");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t stride = gt_images == 1 && batch > 1 ? 0 : c->n0;
+    const uint8_t* m0 = mask_fixed ? mask_fixed : mask_dyn;
+    const uint8_t* m1 = (mask_fixed && mask_dyn) ? mask_dyn : nullptr;
+    ProfScope ps(c, K_MISC);
+    launch_tpr_fpr2(c->stream, gt, stride, m0, m1, (unsigned)mask_value, batch, c->W, c->H,
+                    (unsigned long long*)(mask_fixed ? counts_fixed : counts_dyn), (unsigned long long*)(m1 ? counts_dyn : nullptr));
+    return check_launch("tpr_fpr");
 }
 
 extern "C" int mav_process_batch(mav_ctx* c, const uint8_t* prev, const uint8_t* next, const uint32_t* samples, const double* omega,
@@ -1975,11 +2216,12 @@ static int stage_blur_resize(mav_ctx* c, const uint8_t* img, int k, bool two_pas
     const Layer* l;
     CHK(layer_of(c, k, &l));
     if (!img || !out) return fail(MAV_ERR_ARG, "mav_stage_blur_resize: NULL argument");
-    CHK(ensure_workspace(c));                           // (the two-pass form's scratch)
     const size_t n = (size_t)l->w * l->h;
-    DevBuf di, dout;
-    CHK(di.upload(c, img, c->n0)); CHK(dout.alloc(c, n * sizeof(float)));
-    launch_blur_resize(c->stream, di.as<uint8_t>(), nullptr, 0, c->n0, 1, c->W, c->H, l->w, l->h, blur_of(c, *l), c->ws.Htmp, c->htmp_stride,
+    // the two-pass form's H x w scratch (one frame: 4 bytes per pixel) is a staging block of this call: a diagnostic hook never
+    // allocates the Farneback workspace (GBs at 1080p / 4K) nor freezes "deep_frac"
+    DevBuf di, dout, dtmp;
+    CHK(di.upload(c, img, c->n0)); CHK(dout.alloc(c, n * sizeof(float))); CHK(dtmp.alloc(c, c->htmp_stride * sizeof(float)));
+    launch_blur_resize(c->stream, di.as<uint8_t>(), nullptr, 0, c->n0, 1, c->W, c->H, l->w, l->h, blur_of(c, *l), dtmp.as<float>(), c->htmp_stride,
                        dout.as<float>(), n, two_pass);
     CHK(check_launch("blur_resize"));
     CHK(download(c, out, dout.p, n * sizeof(float)));

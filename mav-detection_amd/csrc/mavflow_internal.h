@@ -125,6 +125,9 @@ void launch_window_max(hipStream_t st, const uint8_t* img, int B, int W, int H, 
                        int64_t* out);
 void launch_tpr_fpr(hipStream_t st, const uint8_t* gt, const uint8_t* mask, unsigned mask_value, int B, int W, int H,
                     unsigned long long* counts /*[B][4]*/);
+// one pass over gt for one mask (mask1 = counts1 = nullptr) or two; gt_stride = 0: one ground-truth image for every pair
+void launch_tpr_fpr2(hipStream_t st, const uint8_t* gt, size_t gt_stride, const uint8_t* mask0, const uint8_t* mask1, unsigned mask_value, int B,
+                     int W, int H, unsigned long long* counts0 /*[B][4]*/, unsigned long long* counts1 /*[B][4]*/);
 void launch_bgr2gray(hipStream_t st, const uint8_t* bgr, size_t n, uint8_t* gray);
 void launch_ransac_only(hipStream_t st, FoeScratch s, int M, int N, double dist2_thr, double* foe);
 void launch_make_derot(hipStream_t st, const double* omega /*null: no rotation*/, const double* dt, const uint8_t* frame0, int B,

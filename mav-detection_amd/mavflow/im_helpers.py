@@ -11,25 +11,26 @@ import numpy as np
 from . import _lib
 from .utils import Rectangle
 
-_CTX_CACHE_SIZES = 2                 # frame sizes kept at one time
+_CTX_CACHE_SIZES = 12                # frame sizes kept at one time (a 1080p image pyramid at scale 1.5 has 9 levels)
 _ctx_cache = {}                      # (W, H) -> Context, least recently used first (dicts keep insertion order)
 
 
 def _ctx(W: int, H: int, batch: int = 1) -> "_lib.Context":
     """A cached context for this frame size.  The reference's helpers are free functions with no state (im_helpers.py:55-84,
-    244-252): the cache holds the contexts of the _CTX_CACHE_SIZES most recently used frame sizes and CLOSES what it drops -- a
-    replaced context (larger batch wanted) and the least recently used size.  Such contexts never compute flow, so each holds
-    only the staging blocks of its calls (no Farneback workspace: mav_create allocates none)."""
+    244-252): the cache holds the contexts of the _CTX_CACHE_SIZES most recently used frame sizes.  Such contexts never compute
+    flow, so each holds only the staging blocks of its calls (no Farneback workspace: mav_create allocates none) -- a dozen idle
+    ones cost a few MB.  A context the cache lets go of (least recently used size, or one replaced by a larger batch) is only
+    DROPPED, never closed: a caller may still hold it (pyramid() across its yields, a loop across its frames) and must find it
+    usable; the library object is destroyed when the last reference goes (Context.__del__)."""
     key = (W, H)
     c = _ctx_cache.pop(key, None)
-    if c is not None and c.max_batch < batch:
-        c.close()
+    if c is not None and (c.max_batch < batch or not c.h):
         c = None
     if c is None:
         c = _lib.Context(W, H, max(batch, 1))
     _ctx_cache[key] = c              # most recently used last
     while len(_ctx_cache) > _CTX_CACHE_SIZES:
-        _ctx_cache.pop(next(iter(_ctx_cache))).close()
+        _ctx_cache.pop(next(iter(_ctx_cache)))
     return c
 
 

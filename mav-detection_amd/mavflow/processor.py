@@ -4,15 +4,24 @@ run_detection() keeps the reference's shape: one frame index at a time, the same
 (:305-341), the same FrameResult fields (:353-362); run_detection_staged() is that loop through the reference-named
 calls one at a time.  run_detection_batched() is the MI355X form of the same loop:
 frame pairs are independent once the flow no longer comes from files, so they go through the fused
-mav_process_batch entry point `batch` pairs at a time.  File / video / PNG output and the homography branch are
-outside the hot path and are not reproduced."""
+mav_process_batch_dev entry point `batch` pairs at a time, two batches in flight.
+
+What the fast loops move (mavflow/pipeline.py): frames (or a host flow field) in; one 32-byte record and eight counts per frame
+out.  Flow, derotated flow and both masks stay on the device as DeviceArray handles (Processor.flow_uv, .estimate_fixed,
+.total_mask) that turn into host arrays the moment somebody reads them; the calculate_tpr_fpr counts of both masks (:350-351) are
+taken on the device against a ground truth that is uploaded once when the dataset declares it constant.
+
+Each loop writes `{results_path}/image_{i:05d}.json` per frame as the reference's write() does (:83-84) when the dataset (or the
+constructor) names a results_path.  Video / PNG output and the homography branch are outside the hot path and are not reproduced."""
 from __future__ import annotations
 
+import json
+import os
 from typing import Dict, Optional, Tuple
 
 import numpy as np
 
-from . import _lib, im_helpers, synth, utils
+from . import _lib, im_helpers, pipeline, synth, utils
 from .detector import Detector
 from .focus_of_expansion import FocusOfExpansion
 from .frame_result import FrameResult
@@ -25,11 +34,14 @@ class SyntheticDataset:
     (use_farneback=True, the seam this build adds) or from the analytic field (the reference's .flo seam)."""
 
     def __init__(self, W: int = 640, H: int = 480, N: int = 6, use_farneback: bool = True, dt: float = 1 / 30.0,
-                 dangle=(0.0, 0.0, 0.0), seed: int = 0):
+                 dangle=(0.0, 0.0, 0.0), seed: int = 0, distinct: Optional[int] = None, results_path: Optional[str] = None):
         self.capture_size = (W, H)
         self.resolution = np.array([W, H])
         self.constant_segmentation = True                # one segmentation image for all frames (Processor derives it once)
+        self.constant_sky_segmentation = True            # ... and one sky mask
         self.N = N
+        self.distinct = distinct                         # pair i shows the content of pair i % distinct (long runs from few pictures)
+        self.results_path = results_path                 # where Processor writes image_%05d.json (dataset.py: results_path)
         self.sequence = f"synthetic-{seed}"
         self.use_farneback = use_farneback
         self.dt = dt
@@ -40,9 +52,12 @@ class SyntheticDataset:
         self._bgr = {}
         self._seg = self._sky = self._depth = None       # the constant images are built once, like files read once
         self._ctx: Optional[_lib.Context] = None
+        self._stage: Optional[pipeline.FlowStage] = None
         self._frame_cursor = 0
 
     def _pair(self, i: int):
+        if self.distinct:
+            i %= self.distinct
         if i not in self._pairs:
             self._pairs[i] = synth.make_pair(self.capture_size[0], self.capture_size[1], self.seed * 1000 + i)
         return self._pairs[i]
@@ -58,15 +73,20 @@ class SyntheticDataset:
             self._bgr[i] = np.repeat(self._pair(i)[1][..., None], 3, axis=2)
         return self._bgr[i]
 
-    def get_flow_uv(self, i: int) -> np.ndarray:
+    def get_flow_uv(self, i: int):
+        """float32 (H, W, 2): the analytic field (a host array, what a .flo file would hold) or libmavflow's Farneback -- then as a
+        pipeline.DeviceArray: array-like, on the device until read, so the loop's next stage takes it from where it is."""
         f0, f1, truth = self._pair(i)
         if not self.use_farneback:
-            return self.get_gt_of(i)                     # the analytic field, float32 (what a .flo file would hold)
+            return self.get_gt_of(i)
         if self._ctx is None:
             self._ctx = _lib.Context(self.capture_size[0], self.capture_size[1], 1)
-        return self._ctx.farneback(f0, f1)[0]
+            self._stage = pipeline.FlowStage(self._ctx)
+        return self._stage.flow_of(f0, f1)
 
     def get_gt_of(self, i: int) -> np.ndarray:
+        if self.distinct:
+            i %= self.distinct
         if i not in self._gt32:
             self._gt32[i] = self._pair(i)[2].astype(np.float32)
         return self._gt32[i]
@@ -105,12 +125,13 @@ class SyntheticDataset:
 
     def release(self) -> None:
         if self._ctx is not None:
+            self._stage.close()
             self._ctx.close()
-            self._ctx = None
+            self._ctx = self._stage = None
 
 
 class Processor:
-    def __init__(self, config: RunConfig) -> None:
+    def __init__(self, config: RunConfig, results_path: Optional[str] = None) -> None:
         self.config = config
         self.logger = config.logger
         self.sequence = config.sequence
@@ -119,32 +140,67 @@ class Processor:
         self.dataset = config.get_dataset()
         self.detector = Detector(self.dataset)
         self.detection_results: Dict[int, FrameResult] = dict()
+        # extra: get_simple_bounding_box of every frame's fixed mask, which the device records with the FoE (the reference derives no
+        # box in this loop; FrameResult and its JSON stay exactly the reference's)
+        self.detection_boxes: Dict[int, utils.Rectangle] = dict()
         self.frame_step_size = 1
         self.frame_index, self.start_frame = 0, 100
         self.is_exiting = False
         self.focus_of_expansion = FocusOfExpansion(self.detector.lucas_kanade)
         self.flow_uv = None
         self._derot, self._derot_frame = None, 0
+        # {results_path}/image_{i:05d}.json per frame (processor.py:83-84); the reference takes the directory from its dataset
+        self.results_path = results_path if results_path is not None else getattr(self.dataset, "results_path", None)
+        self._ctx: Optional[_lib.Context] = None        # this loop's own context (never the helpers' shared, evictable ones)
+        self._pipes: Dict[Tuple[int, int], pipeline.DetectPipeline] = {}
+        self._seg_val = None
+        self._center = None
 
     def is_active(self) -> bool:
         return self.frame_index < self.dataset.N - 1 and not self.is_exiting
 
+    # -- device plumbing --------------------------------------------------------------------------------------------------------
+    def _pipeline(self, ctx: "_lib.Context", batch: int) -> "pipeline.DetectPipeline":
+        key = (id(ctx), batch)
+        pipe = self._pipes.get(key)
+        if pipe is None or pipe.ctx is not ctx or not ctx.h:
+            pipe = pipeline.DetectPipeline(ctx, batch)
+            pipe.foe_params = self.focus_of_expansion._foe_params(1000)
+            self._pipes[key] = pipe
+        return pipe
+
+    def _own_ctx(self, batch: int = 1) -> "_lib.Context":
+        W, H = self.dataset.capture_size
+        if self._ctx is None or not self._ctx.h or self._ctx.max_batch < batch or (self._ctx.W, self._ctx.H) != (W, H):
+            self._close_pipes()
+            if self._ctx is not None:
+                self._ctx.close()
+            self._ctx = _lib.Context(W, H, batch)
+        return self._ctx
+
+    def _close_pipes(self) -> None:
+        for pipe in self._pipes.values():
+            pipe.close()
+        self._pipes = {}
+
     # -- validation tail shared by the loops (processor.py:343-362) ---------------------------------------------------
-    def _fill_result(self, i: int, foe_dense, estimate_fixed, total_mask, sky_scores, masks_on_device: bool = False) -> FrameResult:
+    def _fill_result(self, i: int, foe_dense, sky_scores, counts_fixed=None, counts_dyn=None, estimate_fixed=None, total_mask=None) -> FrameResult:
+        """The FrameResult of frame i.  The TPR / FPR pairs come from the counts the device took of both masks (the fast loops), or,
+        when masks are given instead, from calculate_tpr_fpr on them as the reference's lines read (the staged loop)."""
         r = FrameResult()
         r.foe_dense = foe_dense
         r.foe_gt = utils.assert_type(self.dataset.get_gt_foe(i))
         segmentation, rows, cols = self._segmentation(i)
-        if masks_on_device:      # first thing: both masks are still where the detection call left them on the device, and stay
-            # there only until the next call on that context -- count there (mav_last_masks_tpr_fpr) instead of re-uploading
-            (r.tpr_fixed, r.fpr_fixed), (r.tpr, r.fpr) = im_helpers.tpr_fpr_of_last_masks(segmentation, 255)
         # ground-truth flow of the drone: derotated at the drone's pixels only (pointwise, same values as derotating the frame)
         gt = utils.assert_type(self.dataset.get_gt_of(i))
         with np.errstate(all="ignore"):
             drone_flow_avg_gt = np.average(self.detector.derotate_at(i - self.frame_step_size, i, gt[rows, cols], rows, cols), axis=0)
         center = self._gt_center(segmentation)
         r.center_phi = np.rad2deg(np.arctan2(center[1] - r.foe_gt[1], center[0] - r.foe_gt[0]))
-        if not masks_on_device:
+        if counts_fixed is not None:
+            r.tpr_fixed, r.fpr_fixed = im_helpers._rates(counts_fixed)
+            r.tpr, r.fpr = im_helpers._rates(counts_dyn)
+        else:
             r.tpr_fixed, r.fpr_fixed = im_helpers.calculate_tpr_fpr(segmentation, 255 * estimate_fixed)     # as processor.py:350-351
             r.tpr, r.fpr = im_helpers.calculate_tpr_fpr(segmentation, 255 * total_mask)
         r.sky_tpr, r.sky_fpr = sky_scores
@@ -153,13 +209,21 @@ class Processor:
         r.time = self.dataset.get_time(i)
         return r
 
+    def _store(self, i: int, r: FrameResult) -> None:
+        self.detection_results[i] = r
+        self.config.results[i] = r
+        if self.results_path is not None:                      # what write() leaves per frame (processor.py:83-84), same text
+            os.makedirs(self.results_path, exist_ok=True)
+            with open(f"{self.results_path}/image_{i:05d}.json", "w") as f:
+                f.write(json.dumps(utils.get_json(r), indent=4, sort_keys=True))
+
     def _segmentation(self, i: int):
         """Channel 0 of the dataset's segmentation image, contiguous, with the coordinates of its drone pixels (> 127) and the
         centre of its bounding box (processor.py:332,344-347).  Derived per frame, as the reference's loop does, unless the dataset
         DECLARES its segmentation constant (attribute `constant_segmentation`, SyntheticDataset): then once.  (Caching on the
         array's identity alone would hand a dataset that refills one preallocated array the first frame's pixels for ever.)"""
         seg3 = self.dataset.get_segmentation(i)
-        if getattr(self.dataset, "constant_segmentation", False) and getattr(self, "_seg_val", None) is not None:
+        if getattr(self.dataset, "constant_segmentation", False) and self._seg_val is not None:
             return self._seg_val
         seg = np.ascontiguousarray(seg3[..., 0])
         rows, cols = np.nonzero(seg > 127)
@@ -168,9 +232,7 @@ class Processor:
         return self._seg_val
 
     def _gt_center(self, segmentation: np.ndarray):
-        """get_simple_bounding_box(segmentation).get_center() (processor.py:346-347) of the image _segmentation() last derived.
-        Evaluated on first use, AFTER the detection call's masks have been counted on the device: the box is a device call on the
-        same context and would displace them."""
+        """get_simple_bounding_box(segmentation).get_center() (processor.py:346-347) of the image _segmentation() last derived."""
         if self._center is None:
             self._center = im_helpers.get_simple_bounding_box(segmentation).get_center()
         return self._center
@@ -180,7 +242,7 @@ class Processor:
     @property
     def flow_uv_derotated(self):
         if self._derot is None and self.flow_uv is not None:
-            self._derot = self.detector.derotate(self._derot_frame - self.frame_step_size, self._derot_frame, self.flow_uv)
+            self._derot = self.detector.derotate(self._derot_frame - self.frame_step_size, self._derot_frame, np.asarray(self.flow_uv))
         return self._derot
 
     @flow_uv_derotated.setter
@@ -196,14 +258,29 @@ class Processor:
         dt = self.dataset.get_delta_time(i)
         return np.asarray(self.dataset.get_angular_difference(i - self.frame_step_size, i), np.float64) / dt, dt
 
+    def _sky_and_gt(self, ids):
+        """(submit() keywords for the sky masks and the ground truth of these frames, their segmentation tuples).  A dataset that declares
+        an image constant has it uploaded once for the run; otherwise one image per frame travels with the batch."""
+        kw = {}
+        skies = [self.dataset.get_sky_segmentation(i) for i in ids]
+        if getattr(self.dataset, "constant_sky_segmentation", False):
+            kw["sky_shared"] = skies[0]
+        else:
+            kw["sky"] = skies
+        segs = [self._segmentation(i) for i in ids]
+        if getattr(self.dataset, "constant_segmentation", False):
+            kw["gt_shared"] = segs[0][0]
+        else:
+            kw["gt"] = [sg[0] for sg in segs]
+        return kw, skies
+
     def run_detection(self) -> Dict[int, FrameResult]:
-        """The reference's loop (processor.py:283-341): one frame index at a time, flow from the dataset's seam
-        (get_flow_uv: a .flo file or Farneback on the GPU), then derotation -> FoE -> phi -> masks in ONE device call
-        (mav_detect): the float32 field crosses PCIe once, the masks come back, nothing else moves.  Frame 0 takes the
-        reference's float32 path (detector.py:80-81).  The sample coordinates are drawn from np.random exactly where
-        get_FOE_dense draws them."""
-        W, H = self.dataset.capture_size
-        ctx = im_helpers._ctx(W, H)
+        """The reference's loop (processor.py:283-341): one frame index at a time, flow from the dataset's seam (get_flow_uv: a
+        .flo file -> a host array, or Farneback on the GPU -> a DeviceArray), then derotation -> FoE -> phi -> masks -> box -> the
+        calculate_tpr_fpr counts of both masks in ONE enqueue on the context that holds the flow (pipeline.DetectPipeline): a host
+        field crosses PCIe once, a device field not at all; a 32-byte record and eight counts come back.  estimate_fixed /
+        total_mask are DeviceArray handles (read them and they are host arrays).  Frame 0 takes the reference's float32 path
+        (detector.py:80-81).  The sample coordinates are drawn from np.random exactly where get_FOE_dense draws them."""
         while self.is_active():
             i = self.frame_index
             self.dataset.get_frame()
@@ -211,25 +288,26 @@ class Processor:
             if self.flow_uv is None:
                 raise ValueError("Could not load flow field.")
             self._derot, self._derot_frame = None, i
-            if np.asarray(self.flow_uv).dtype != np.float32:
+            if self.flow_uv.dtype != np.float32:
                 # a float64 field is evaluated in float64 from the start by the reference: the fused float32 call would narrow
                 # it, so this frame goes through the float64 kernels (the staged calls)
                 self._staged_frame(i)
                 continue
-            self.sky_mask = self.dataset.get_sky_segmentation(i)
+            on_dev = isinstance(self.flow_uv, pipeline.DeviceArray) and self.flow_uv.on_device
+            pipe = self._pipeline(self.flow_uv.ctx if on_dev else self._own_ctx(1), 1)
+            kw, skies = self._sky_and_gt([i])
+            self.sky_mask = skies[0]
             sky = self.dataset.validate_sky_segment(self.sky_mask, utils.assert_type(self.dataset.get_depth(i)))
             rand1 = np.zeros((2000, 2), dtype=np.uint32)                 # focus_of_expansion.py:69-71
             rand1[..., 0] = np.random.randint(0, self.flow_uv.shape[0], 2000)
             rand1[..., 1] = np.random.randint(0, self.flow_uv.shape[1], 2000)
             omega, dt = self._rates(i) if i >= 1 else (np.zeros(3), 1.0)
-            out = ctx.detect(self.flow_uv, rand1, omega=omega, dt=dt, sky=self.sky_mask, frame0=[i < 1],
-                             foe_params=self.focus_of_expansion._foe_params(1000))
+            out = pipe.collect(pipe.submit(rand1, flow=self.flow_uv, omega=omega, dt=dt, frame0=[i < 1], **kw))
             rec = out["results"][0]
             self.estimate_fixed, self.total_mask = out["mask_fixed"][0], out["mask_dyn"][0]
-            r = self._fill_result(i, (float(rec["foe"][0]), float(rec["foe"][1])), self.estimate_fixed, self.total_mask, sky,
-                                  masks_on_device=True)
-            self.detection_results[i] = r
-            self.config.results[i] = r
+            r = self._fill_result(i, (float(rec["foe"][0]), float(rec["foe"][1])), sky, out["counts_fixed"][0], out["counts_dyn"][0])
+            self.detection_boxes[i] = utils.Rectangle.from_box(rec["box"])
+            self._store(i, r)
             self.frame_index += 1
         return self.detection_results
 
@@ -249,47 +327,60 @@ class Processor:
     def _staged_frame(self, i: int) -> None:
         """One frame through the reference-named calls (processor.py:306-341), flow already in self.flow_uv."""
         self._derot_frame = i
-        self.flow_uv_derotated = self.detector.derotate(i - self.frame_step_size, i, self.flow_uv)
+        self.flow_uv_derotated = self.detector.derotate(i - self.frame_step_size, i, np.asarray(self.flow_uv))
         self.sky_mask = self.dataset.get_sky_segmentation(i)
         sky = self.dataset.validate_sky_segment(self.sky_mask, utils.assert_type(self.dataset.get_depth(i)))
         foe = self.focus_of_expansion.get_FOE_dense(self.flow_uv_derotated)
         fixed, total = self.focus_of_expansion.get_masks(self.flow_uv_derotated, foe, self.sky_mask)
         self.estimate_fixed, self.total_mask = fixed, total
-        r = self._fill_result(i, foe, fixed, total, sky)
-        self.detection_results[i] = r
-        self.config.results[i] = r
+        r = self._fill_result(i, foe, sky, estimate_fixed=fixed, total_mask=total)
+        self._store(i, r)
         self.frame_index += 1
 
     def run_detection_batched(self, batch: int = 8) -> Dict[int, FrameResult]:
-        """The same loop with frame pairs in flight `batch` at a time through the fused entry point (frames -> flow ->
-        derotation -> FoE -> masks -> box).  Needs a dataset that hands out frame pairs (frame_pair(i))."""
+        """The same loop with frame pairs in flight `batch` at a time through the fused entry point (frames -> flow -> derotation ->
+        FoE -> masks -> box -> counts), two batches in flight: while batch k computes, batch k + 1's frames are gathered from the
+        dataset's arrays and cross PCIe, and batch k - 1's FrameResults are filled in.  Needs a dataset that hands out frame pairs
+        (frame_pair(i)).  The sample coordinates are drawn per frame in frame order, as get_FOE_dense draws them."""
         W, H = self.dataset.capture_size
         idx = list(range(self.frame_index, self.dataset.N - 1))
-        with _lib.Context(W, H, batch) as ctx:
-            for b0 in range(0, len(idx), batch):
-                ids = idx[b0:b0 + batch]
-                prev = np.stack([self.dataset.frame_pair(i)[0] for i in ids])
-                nxt = np.stack([self.dataset.frame_pair(i)[1] for i in ids])
-                samples = np.zeros((len(ids), 2000, 2), np.uint32)
-                for k in range(len(ids)):                      # same draws, same order as get_FOE_dense
-                    samples[k, :, 0] = np.random.randint(0, H, 2000)
-                    samples[k, :, 1] = np.random.randint(0, W, 2000)
-                dts = np.array([self.dataset.get_delta_time(i) for i in ids], np.float64)
-                rot = [i >= 1 for i in ids]
-                omega = np.stack([np.asarray(self.dataset.get_angular_difference(i - 1, i), np.float64) / dt
-                                  for i, dt in zip(ids, dts)])
-                # frame 0 is never derotated and runs in float32 (detector.py:80-81): flagged per pair below
-                sky = np.stack([self.dataset.get_sky_segmentation(i) for i in ids])
-                out = ctx.process_batch(prev, nxt, samples, omega=omega, dt=dts, sky=sky, frame0=[not r_ for r_ in rot])
-                for k, i in enumerate(ids):
-                    rec = out["results"][k]
-                    r = self._fill_result(i, (float(rec["foe"][0]), float(rec["foe"][1])), out["mask_fixed"][k], out["mask_dyn"][k],
-                                          (0.0, 0.0))
-                    r.box = utils.Rectangle.from_box(rec["box"])   # extra: the detection box (the reference never stores one)
-                    self.detection_results[i] = r
-                    self.config.results[i] = r
+        pipe = self._pipeline(self._own_ctx(batch), batch)
+        pending = None
+        for b0 in range(0, len(idx), batch):
+            ids = idx[b0:b0 + batch]
+            pairs = [self.dataset.frame_pair(i) for i in ids]
+            samples = np.empty((len(ids), 2000, 2), np.uint32)
+            for k in range(len(ids)):                      # same draws, same order as get_FOE_dense
+                samples[k, :, 0] = np.random.randint(0, H, 2000)
+                samples[k, :, 1] = np.random.randint(0, W, 2000)
+            dts = np.array([self.dataset.get_delta_time(i) for i in ids], np.float64)
+            # frame 0 is never derotated and runs in float32 (detector.py:80-81): flagged per pair
+            omega = np.stack([np.asarray(self.dataset.get_angular_difference(i - self.frame_step_size, i), np.float64) / dt
+                              for i, dt in zip(ids, dts)])
+            kw, skies = self._sky_and_gt(ids)
+            sky_scores = [self.dataset.validate_sky_segment(sk, utils.assert_type(self.dataset.get_depth(i))) for i, sk in zip(ids, skies)]
+            ticket = pipe.submit(samples, prev=[p[0] for p in pairs], nxt=[p[1] for p in pairs], omega=omega, dt=dts,
+                                 frame0=[i < 1 for i in ids], **kw)
+            if pending is not None:
+                self._finish_batch(pipe, *pending)
+            pending = (ids, ticket, sky_scores)
+        if pending is not None:
+            self._finish_batch(pipe, *pending)
         self.frame_index = self.dataset.N - 1
         return self.detection_results
 
+    def _finish_batch(self, pipe, ids, ticket, sky_scores) -> None:
+        out = pipe.collect(ticket)
+        for k, i in enumerate(ids):
+            rec = out["results"][k]
+            r = self._fill_result(i, (float(rec["foe"][0]), float(rec["foe"][1])), sky_scores[k], out["counts_fixed"][k], out["counts_dyn"][k])
+            self.detection_boxes[i] = utils.Rectangle.from_box(rec["box"])
+            self._store(i, r)
+        self.estimate_fixed, self.total_mask = out["mask_fixed"][-1], out["mask_dyn"][-1]     # of the last frame, as the loop leaves them
+
     def release(self) -> None:
+        self._close_pipes()
+        if self._ctx is not None:
+            self._ctx.close()
+            self._ctx = None
         self.dataset.release()

@@ -47,17 +47,40 @@ def test_the_workspace_comes_with_the_first_flow_call_and_stays(mav):
         assert ws > 0
         f2 = ctx.farneback(prev, nxt)
         assert ctx.mem_info()["workspace_bytes"] == ws and np.array_equal(f1, f2)
-        # a stage hook that needs the two-pass scratch allocates on a fresh context too
+        # a stage hook that needs the two-pass scratch takes a staging block of its own: no Farneback workspace, and "deep_frac"
+        # (settable until the first call that computes flow) stays open
     with _lib.Context(W, H, 1) as ctx:
         a = ctx.stage_blur_resize(prev[0], 1, two_pass=True)
-        assert ctx.mem_info()["workspace_bytes"] > 0
+        assert ctx.mem_info()["workspace_bytes"] == 0
         assert np.array_equal(a, ctx.stage_blur_resize(prev[0], 1))
+        ctx.set_option("deep_frac", 32)
 
 
-def test_helper_context_cache_is_bounded_and_closes_what_it_drops(mav):
+def test_deep_layer_workspace_arrives_with_the_first_call_of_more_than_one_group(mav):
+    """The deep layers' work set is reachable only by calls of more than one group: a context whose calls stay within one group never
+    holds it, and mav_mem_info's workspace figure grows by exactly that set when the first such call comes."""
+    from mavflow import _lib
+    W, H, B = 320, 240, 6
+    prev, nxt = synth.make_batch(W, H, B, distinct=2)
+    with _lib.Context(W, H, B) as ctx:
+        ctx.set_option("group", 2)
+        one = ctx.farneback(prev[:2], nxt[:2]).copy()            # one group: no deep set
+        ws1 = ctx.mem_info()["workspace_bytes"]
+        all6 = ctx.farneback(prev, nxt)                           # three groups: the deep layers run once for the call
+        ws2 = ctx.mem_info()["workspace_bytes"]
+        assert ws2 > ws1 > 0
+        assert np.array_equal(all6[:2], one)
+        ctx.farneback(prev, nxt)
+        assert ctx.mem_info()["workspace_bytes"] == ws2
+
+
+def test_helper_context_cache_is_bounded_and_a_held_context_survives_eviction(mav):
+    """The helpers' context cache keeps the most recently used frame sizes and only DROPS what falls out -- it never closes a context,
+    because a caller may still hold it: pyramid() across its yields, a loop across its frames."""
     from mavflow import im_helpers
     im_helpers._ctx_cache.clear()
-    sizes = [(64, 48), (80, 60), (96, 72)]
+    cap = im_helpers._CTX_CACHE_SIZES
+    sizes = [(64 + 16 * k, 48 + 12 * k) for k in range(cap + 2)]
     seen = []
     for (W, H) in sizes:
         img = np.zeros((H, W), np.uint8)
@@ -65,12 +88,36 @@ def test_helper_context_cache_is_bounded_and_closes_what_it_drops(mav):
         r = im_helpers.get_simple_bounding_box(img)
         assert r.get_topleft() == (7, 5)
         seen.append(im_helpers._ctx_cache[(W, H)])
-    assert list(im_helpers._ctx_cache) == sizes[1:]               # two sizes kept, the oldest dropped ...
-    assert seen[0].h is None                                      # ... and closed
-    im_helpers.get_simple_bounding_box(np.zeros((60, 80), np.uint8))
-    assert list(im_helpers._ctx_cache) == [sizes[2], sizes[1]]    # a hit moves to the back
-    c = im_helpers._ctx(96, 72, batch=4)                          # a larger batch replaces (and closes) the cached context
-    assert c.max_batch == 4 and seen[2].h is None
+    assert list(im_helpers._ctx_cache) == sizes[2:]               # `cap` sizes kept, the two oldest dropped ...
+    assert seen[0].h is not None                                  # ... but NOT closed: the handle we hold still works
+    img = np.zeros((sizes[0][1], sizes[0][0]), np.uint8)
+    img[3, 4] = 9
+    assert tuple(seen[0].bbox(img)[0]) == (4, 3, 4, 3)
+    im_helpers.get_simple_bounding_box(np.zeros((sizes[3][1], sizes[3][0]), np.uint8))
+    assert list(im_helpers._ctx_cache)[-1] == sizes[3]            # a hit moves to the back
+    c = im_helpers._ctx(*sizes[4], batch=4)                       # a larger batch replaces the cached context, the old one stays usable
+    assert c.max_batch == 4 and seen[4].h is not None and c is not seen[4]
+    im_helpers._ctx_cache.clear()
+
+
+def test_pyramid_generator_survives_helper_calls_on_every_level_size(mav):
+    """pyramid() holds its context across yields; calling a helper on each level's own size (more sizes than the cache keeps would
+    evict that context) must not break the next level."""
+    from mavflow import im_helpers
+    im_helpers._ctx_cache.clear()
+    keep = im_helpers._CTX_CACHE_SIZES
+    im_helpers._CTX_CACHE_SIZES = 2
+    try:
+        img = (np.add.outer(np.arange(540), np.arange(960)) % 251).astype(np.uint8)
+        levels = []
+        for lv in im_helpers.pyramid(img, scale=1.5):
+            box = im_helpers.get_simple_bounding_box(lv)          # a context of this level's size: evicts the generator's
+            assert box.get_topleft()[0] >= 0
+            levels.append(lv.shape)
+        assert len(levels) >= 6 and levels[0] == (540, 960)
+    finally:
+        im_helpers._CTX_CACHE_SIZES = keep
+        im_helpers._ctx_cache.clear()
 
 
 def test_two_contexts_in_two_threads_are_independent(mav):

@@ -132,7 +132,7 @@ def test_processor_loops_agree_with_the_oracle(mav):
     res_s = p3.run_detection_staged()          # the reference-named calls one by one
     assert sorted(res) == sorted(res_b) == sorted(res_s) == [0, 1, 2]
     for i in res:                              # frame 0 (float32 path) and the later frames agree across all three loops
-        assert vars(res[i]) == vars(res_s[i]), i
+        assert vars(res[i]) == vars(res_s[i]) == vars(res_b[i]), i
         assert np.array_equal(p1.estimate_fixed, p3.estimate_fixed) and np.array_equal(p1.total_mask, p3.total_mask)
     # the oracle, fed the same flow and the same random draws
     np.random.seed(11)
@@ -149,8 +149,10 @@ def test_processor_loops_agree_with_the_oracle(mav):
             exp = fo.calculate_tpr_fpr(seg, 255 * ref["fixed"])
         assert (res[i].tpr_fixed, res[i].fpr_fixed) == tuple(exp) == (res_b[i].tpr_fixed, res_b[i].fpr_fixed)
         assert res[i].drone_size_pixels == 24 * 24 and res[i].time == i * ds1.dt
-        assert tuple(int(v) for v in (res_b[i].box.topleft + res_b[i].box.size)) == \
-            (ref["box"][0], ref["box"][1], ref["box"][2] - ref["box"][0], ref["box"][3] - ref["box"][1])
+        for p_ in (p1, p2):
+            bx = p_.detection_boxes[i]
+            assert tuple(int(v) for v in (bx.topleft + bx.size)) == \
+                (ref["box"][0], ref["box"][1], ref["box"][2] - ref["box"][0], ref["box"][3] - ref["box"][1])
 
 
 def test_float64_flow_keeps_its_precision_and_loop_attributes_exist(mav):
