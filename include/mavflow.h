@@ -219,6 +219,8 @@ int mav_detect_dev(mav_ctx*, const float* flow, const uint32_t* samples, const d
 /* Device pointer of the flow field the most recent mav_process_batch_dev / mav_farneback_dev call on this context wrote
  * (the caller's buffer, or the context's own workspace when the caller passed flow == NULL); NULL before the first call.
  * Lets a caller that keeps the flow in the workspace (bench.py) still inspect it. */
+/* cv2.cvtColor(COLOR_BGR2GRAY) [src/farneback.py:21,74] on device pointers: (batch, H, W, 3) u8 -> (batch, H, W) u8. */
+int mav_bgr2gray_dev(mav_ctx*, const uint8_t* bgr, int batch, uint8_t* gray);
 const float* mav_last_flow_dev(const mav_ctx*);
 /* im_helpers.calculate_tpr_fpr [src/im_helpers.py:244-252, called at src/processor.py:350-351] for device-resident masks against a
  * device-resident ground truth, counts left on the device (4 x int64 per pair: positives, negatives, true / false positives): the
@@ -269,6 +271,12 @@ int mav_marker_create(mav_ctx*, void** marker_out);
 int mav_marker_record(mav_ctx*, void* marker);
 int mav_marker_wait(mav_ctx*, void* marker);
 int mav_marker_destroy(mav_ctx* /* may be NULL */, void* marker);
+
+/* Frame decode in front of the path [src/datasets/dataset.py:57,223-230: cv2.VideoCapture over image_%05d.png; src/farneback.py:17-21]:
+ * the un-filtering pass of a PNG image, host memory, no context.  raw = the inflated IDAT stream of a non-interlaced image (per row a
+ * filter-type byte + stride bytes), bpp = bytes per complete pixel (1 for bit depths below 8), out = rows x stride bytes.  Filters 0 - 4 of
+ * the PNG specification.  MAV_ERR_ARG for any other filter type.  (zlib inflate and chunk parsing: mavflow/frame_source.py, Python stdlib.) */
+int mav_png_unfilter(const uint8_t* raw, int rows, size_t stride, int bpp, uint8_t* out);
 
 /* HIP-event timing on the context's stream (bench.py): start/stop bracket enqueued work; stop synchronises. */
 int mav_timer_start(mav_ctx*);

@@ -6,6 +6,7 @@
 #include <float.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -1884,6 +1885,59 @@ extern "C" int mav_bgr2gray(mav_ctx* c, const uint8_t* bgr, int batch, uint8_t* 
     CHK(check_launch("bgr2gray"));
     CHK(download(c, gray, dg.p, n));
     return mav_sync(c);
+}
+
+extern "C" int mav_bgr2gray_dev(mav_ctx* c, const uint8_t* bgr, int batch, uint8_t* gray)
+{
+    if (!c || !bgr || !gray) return fail(MAV_ERR_ARG, "mav_bgr2gray_dev: NULL argument");
+    if (batch < 1) return fail(MAV_ERR_ARG, "mav_bgr2gray_dev: batch %d < 1", batch);
+    HIPCHK(hipSetDevice(c->device));
+    ProfScope ps(c, K_MISC);
+    launch_bgr2gray(c->stream, bgr, c->n0 * (size_t)batch, gray);
+    return check_launch("bgr2gray");
+}
+
+// ---- frame decode, host side: the un-filtering pass of a PNG image ------------------------------------------------------------------
+// `raw` is the inflated IDAT stream of a non-interlaced image: per row one filter-type byte followed by `stride` bytes; bpp = bytes per
+// complete pixel (1 for depths below 8).  Filters 0 - 4 of the PNG specification (None, Sub, Up, Average, Paeth), arithmetic modulo 256.
+// Sub / Average / Paeth are recurrences along the row, Up / Average / Paeth along the column: inherently serial per image, a few
+// milliseconds of plain C for a 1080p frame (a numpy formulation needs a Python-level loop per pixel for two of the five filters).
+extern "C" int mav_png_unfilter(const uint8_t* raw, int rows, size_t stride, int bpp, uint8_t* out)
+{
+    if (!raw || !out || rows < 0 || bpp < 1 || bpp > 8) return fail(MAV_ERR_ARG, "mav_png_unfilter: bad argument");
+    const uint8_t* prev = nullptr;
+    for (int y = 0; y < rows; y++) {
+        const uint8_t ft = raw[(size_t)y * (stride + 1)];
+        const uint8_t* in = raw + (size_t)y * (stride + 1) + 1;
+        uint8_t* o = out + (size_t)y * stride;
+        const size_t b = (size_t)bpp;
+        switch (ft) {
+        case 0: memcpy(o, in, stride); break;
+        case 1:
+            for (size_t i = 0; i < stride; i++) o[i] = (uint8_t)(in[i] + (i >= b ? o[i - b] : 0));
+            break;
+        case 2:
+            for (size_t i = 0; i < stride; i++) o[i] = (uint8_t)(in[i] + (prev ? prev[i] : 0));
+            break;
+        case 3:
+            for (size_t i = 0; i < stride; i++) {
+                const unsigned a = i >= b ? o[i - b] : 0, up = prev ? prev[i] : 0;
+                o[i] = (uint8_t)(in[i] + ((a + up) >> 1));
+            }
+            break;
+        case 4:
+            for (size_t i = 0; i < stride; i++) {
+                const int a = i >= b ? o[i - b] : 0, up = prev ? prev[i] : 0, ul = (prev && i >= b) ? prev[i - b] : 0;
+                const int p = a + up - ul, pa = abs(p - a), pb = abs(p - up), pc = abs(p - ul);
+                const int pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? up : ul);
+                o[i] = (uint8_t)(in[i] + pred);
+            }
+            break;
+        default: return fail(MAV_ERR_ARG, "mav_png_unfilter: row %d has filter type %d (valid: 0 - 4)", y, (int)ft);
+        }
+        prev = o;
+    }
+    return MAV_OK;
 }
 
 extern "C" int mav_ransac(mav_ctx* c, const double* estimates, int count, double ransac_threshold, double* foe)

@@ -52,7 +52,7 @@ EXPORTS = [
     "mav_stage_phi_mask", "mav_last_masks_tpr_fpr", "mav_get_option", "mav_schedule_info", "mav_stage_blur_resize_two_pass",
     "mav_membw_probe", "mav_runtime_info", "mav_upload_async_unordered", "mav_mem_info", "mav_profile_intervals",
     "mav_upload_gather", "mav_download_async", "mav_marker_create", "mav_marker_record", "mav_marker_wait", "mav_marker_destroy",
-    "mav_tpr_fpr_counts_dev",
+    "mav_tpr_fpr_counts_dev", "mav_bgr2gray_dev", "mav_png_unfilter",
 ]
 
 _lib = None
@@ -136,6 +136,8 @@ def load(path: str | None = None) -> C.CDLL:
     lib.mav_marker_wait.argtypes = [vp, vp]
     lib.mav_marker_destroy.argtypes = [vp, vp]
     lib.mav_tpr_fpr_counts_dev.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp]
+    lib.mav_bgr2gray_dev.argtypes = [vp, vp, C.c_int, vp]
+    lib.mav_png_unfilter.argtypes = [vp, C.c_int, C.c_size_t, C.c_int, vp]
     lib.mav_timer_start.argtypes = [vp]
     lib.mav_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
     lib.mav_profile_enable.argtypes = [vp, C.c_int]

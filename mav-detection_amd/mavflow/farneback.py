@@ -69,6 +69,16 @@ class Farneback:
         self.history_length = 1
         self.prev_result = np.zeros((H, W, 3), np.uint8)
 
+    @classmethod
+    def from_png_sequence(cls, img_path: str, img_format: str = "image_%05d.png", output=None) -> "Farneback":
+        """Farneback(cv2.VideoCapture(f'{img_path}/image_%05d.png'), output) with the capture this build provides for PNG sequences
+        (frame_source.PngSequenceCapture; src/datasets/dataset.py:38,57)."""
+        from .frame_source import PngSequenceCapture
+        cap = PngSequenceCapture(f"{img_path}/{img_format}")
+        if not cap.isOpened():
+            raise OSError(f"no PNG sequence at {img_path}/{img_format}")
+        return cls(cap, output)
+
     def _gray(self, img: np.ndarray) -> np.ndarray:
         return self.ctx.bgr2gray(img)[0] if img.ndim == 3 else np.ascontiguousarray(img, np.uint8)
 

@@ -41,7 +41,9 @@ class FarnebackFlowProvider:
     changing; the fields are bit-identical to the one-pair calls."""
 
     def __init__(self, get_gray: Callable[[int], np.ndarray], width: int, height: int, img_path: Optional[str] = None,
-                 write_flo: bool = False, window: int = 1, n_frames: Optional[int] = None) -> None:
+                 write_flo: bool = False, window: int = 1, n_frames: Optional[int] = None, on_device: bool = False) -> None:
+        """on_device (window = 1): get_flow_uv returns a pipeline.DeviceArray -- the field stays on the GPU until somebody reads it,
+        which Processor.run_detection never does (BGR frames are converted there too); off by default: a host float32 array."""
         from . import _lib
         self.get_gray, self.img_path, self.write_flo = get_gray, img_path, write_flo
         if window < 1 or (window > 1 and n_frames is None):
@@ -49,14 +51,40 @@ class FarnebackFlowProvider:
         self.window, self.n_frames = int(window), n_frames
         self.ctx = _lib.Context(width, height, self.window)
         self._cache: dict = {}
+        self._stage = None
+        if on_device:
+            if self.window != 1:
+                raise ValueError("on_device needs window = 1")
+            from . import pipeline
+            self._stage = pipeline.FlowStage(self.ctx)
         if write_flo and not img_path:
             raise ValueError("write_flo needs img_path")
+
+    @classmethod
+    def from_png_sequence(cls, img_path: str, img_format: str = "image_%05d.png", **kw) -> "FarnebackFlowProvider":
+        """The reference's frame layout (src/datasets/dataset.py:26,38: `{img_path}/image_%05d.png`) as the source of the frames: frame i
+        = cv2.imread of file i (frame_source.imread), converted BGR -> gray on the GPU."""
+        from . import frame_source
+        pattern = f"{img_path}/{img_format}"
+        first = frame_source.imread(pattern % 0)
+        if first is None:
+            raise OSError(f"cannot read {pattern % 0}")
+
+        def get(i: int) -> np.ndarray:
+            f = frame_source.imread(pattern % i)
+            if f is None:
+                raise OSError(f"cannot read {pattern % i}")
+            return f
+        kw.setdefault("img_path", img_path)
+        return cls(get, first.shape[1], first.shape[0], **kw)
 
     def _gray(self, i: int) -> np.ndarray:
         f = np.asarray(self.get_gray(i))
         return self.ctx.bgr2gray(f)[0] if f.ndim == 3 else np.ascontiguousarray(f, np.uint8)
 
     def _compute(self, i: int) -> np.ndarray:
+        if self._stage is not None:
+            return self._stage.flow_of(self.get_gray(i), self.get_gray(i + 1))
         if self.window == 1:
             return self.ctx.farneback(self._gray(i), self._gray(i + 1))[0]
         if i not in self._cache:
@@ -70,8 +98,10 @@ class FarnebackFlowProvider:
         if self.write_flo:
             path = flo_path(self.img_path, i)
             os.makedirs(os.path.dirname(path), exist_ok=True)
-            utils.write_flow(path, flow)
+            utils.write_flow(path, np.asarray(flow))
         return flow
 
     def release(self) -> None:
+        if self._stage is not None:
+            self._stage.close()
         self.ctx.close()

@@ -136,38 +136,79 @@ def _ptr_array(arrays):
 
 
 class FlowStage:
-    """cv2.calcOpticalFlowFarneback(prev, next, ...) (src/farneback.py:76-80) whose result stays where the next stage reads it."""
+    """cv2.calcOpticalFlowFarneback(prev, next, ...) (src/farneback.py:76-80) whose result stays where the next stage reads it.
+    Frames are (H, W) u8 gray or (H, W, 3) u8 BGR as a capture hands them out; BGR frames are converted on the device
+    (cv2.cvtColor(COLOR_BGR2GRAY), src/farneback.py:21,74 -> mav_bgr2gray_dev)."""
 
     def __init__(self, ctx: "_lib.Context"):
         self.ctx = ctx
         n0 = ctx.W * ctx.H
-        self._frames = ctx.alloc(2 * n0)
+        self._gray = ctx.alloc(2 * n0)                    # the two frames of the pair being computed
+        self._bgr = None                                  # staging of BGR frames (first BGR frame allocates it)
         self._flow = [ctx.alloc(8 * n0), ctx.alloc(8 * n0)]
         self._handles = [[], []]
         self._turn = 0
+        self._have_prev = False                           # video mode (flow_next): slot of the previous frame
+        self._prev_slot = 0
 
-    def flow_of(self, prev: np.ndarray, nxt: np.ndarray) -> DeviceArray:
-        """Flow prev -> next as a DeviceArray (H, W, 2) float32.  The handle stays valid: the buffer it points to is re-used by the
-        call after the next one, which first brings a still-referenced handle over to the host."""
-        ctx = self.ctx
-        f = _as_frames((prev, nxt), ctx.H, ctx.W, "frame")
+    def _upload(self, frames, slots, ordered: int) -> None:
+        """frames[k] -> gray slot slots[k] (0 / 1) of the pair buffer."""
+        ctx, n0 = self.ctx, self.ctx.W * self.ctx.H
+        arrs = []
+        for k, f in enumerate(frames):
+            a = np.asarray(f)
+            if a.dtype != np.uint8 or a.shape[:2] != (ctx.H, ctx.W) or not (a.ndim == 2 or (a.ndim == 3 and a.shape[2] == 3)):
+                raise ValueError(f"frame {k}: expected ({ctx.H}, {ctx.W}) or ({ctx.H}, {ctx.W}, 3) uint8, got {a.shape} {a.dtype}")
+            arrs.append(a if a.flags.c_contiguous else np.ascontiguousarray(a))
+        gray = [(a, sl) for a, sl in zip(arrs, slots) if a.ndim == 2]
+        bgr = [(a, sl) for a, sl in zip(arrs, slots) if a.ndim == 3]
+        if len(gray) == 2 and slots == [0, 1]:
+            check(ctx.lib.mav_upload_gather(ctx.h, self._gray.ptr, _ptr_array([g[0] for g in gray]), 2, n0, ordered))
+        else:
+            for a, sl in gray:
+                check(ctx.lib.mav_upload_gather(ctx.h, self._gray.ptr + sl * n0, _ptr_array([a]), 1, n0, ordered))
+        if bgr:
+            if self._bgr is None:
+                self._bgr = ctx.alloc(6 * n0)
+            for j, (a, sl) in enumerate(bgr):
+                check(ctx.lib.mav_upload_gather(ctx.h, self._bgr.ptr + j * 3 * n0, _ptr_array([a]), 1, 3 * n0, 1))
+        check(ctx.lib.mav_upload_fence(ctx.h))
+        for j, (a, sl) in enumerate(bgr):
+            check(ctx.lib.mav_bgr2gray_dev(ctx.h, self._bgr.ptr + j * 3 * n0, 1, self._gray.ptr + sl * n0))
+
+    def _flow_into_next_buffer(self, prev_slot: int, next_slot: int) -> DeviceArray:
+        ctx, n0 = self.ctx, self.ctx.W * self.ctx.H
         k = self._turn
         self._turn ^= 1
         _retire_all(self._handles[k])
-        n0 = ctx.W * ctx.H
-        # ordered: the previous call's flow kernels may still read the frame buffer
-        check(ctx.lib.mav_upload_gather(ctx.h, self._frames.ptr, _ptr_array(f), 2, n0, 1))
-        check(ctx.lib.mav_upload_fence(ctx.h))
-        ctx.farneback_dev(self._frames.ptr, self._frames.ptr + n0, 1, self._flow[k].ptr)
+        ctx.farneback_dev(self._gray.ptr + prev_slot * n0, self._gray.ptr + next_slot * n0, 1, self._flow[k].ptr)
         h = DeviceArray(ctx, self._flow[k].ptr, (ctx.H, ctx.W, 2), np.float32)
         self._handles[k].append(weakref.ref(h))
         return h
 
+    def flow_of(self, prev: np.ndarray, nxt: np.ndarray) -> DeviceArray:
+        """Flow prev -> next as a DeviceArray (H, W, 2) float32.  The handle stays valid: the buffer it points to is re-used by the
+        call after the next one, which first brings a still-referenced handle over to the host."""
+        self._have_prev = False
+        self._upload([prev, nxt], [0, 1], 1)             # ordered: the previous call's flow kernels may still read the pair buffer
+        return self._flow_into_next_buffer(0, 1)
+
+    def flow_next(self, frame: np.ndarray) -> Optional[DeviceArray]:
+        """Video mode, the reference's Farneback.process() (src/farneback.py:73-81): the flow from the previous frame handed in to this
+        one; the previous frame's gray image is still on the device (the class's `prevgray`), so one frame crosses PCIe per step.
+        None for the first frame."""
+        slot = self._prev_slot ^ 1 if self._have_prev else 0
+        self._upload([frame], [slot], 1)
+        out = self._flow_into_next_buffer(self._prev_slot, slot) if self._have_prev else None
+        self._have_prev, self._prev_slot = True, slot
+        return out
+
     def close(self):
         for hs in self._handles:
             _retire_all(hs)
-        for b in [self._frames] + self._flow:
-            b.free()
+        for b in [self._gray, self._bgr] + self._flow:
+            if b is not None:
+                b.free()
 
 
 class _Slot:
