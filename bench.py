@@ -28,7 +28,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s 
 ITER_BYTES_UPDATE = 88           # SURVEY 8d's model, per pixel per sweep: read M 20 + R0 20 + R1 20, write M' 20 + flow 8
 ITER_BYTES_MOVED = 80            # what the kernel has to move: the flow of an updating sweep is consumed inside the kernel (store_flow = 0)
 ITER_BYTES_LAST = 28             # last sweep of a layer: read M 20, write flow 8
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 
 
 def b_alg_per_pair(layers, W, H, iters):
@@ -333,7 +333,7 @@ def run_config_leg(name, W, H, B, levels, calls, pairs_to_check, verify=True, ce
     return out
 
 
-def api_loop_leg(W=1920, H=1080, batch=64, n_batches=6, n_unbatched=96, staged=False, breakdown=False):
+def api_loop_leg(W=1920, H=1080, batch=64, n_batches=6, n_unbatched=96, staged=False, only_batched=False):
     """The door north_star says users come through: the reference-shaped loops of mavflow.processor on a pre-generated synthetic
     dataset -- host numpy frames in (pageable, one array per frame, as Dataset hands them out), filled FrameResults out.  Never
     `value`.  Each loop runs once to warm its context (workspace allocation, first launches) and is timed on its second run over the
@@ -372,6 +372,8 @@ def api_loop_leg(W=1920, H=1080, batch=64, n_batches=6, n_unbatched=96, staged=F
     dt, res_b = timed(p, ds, lambda: p.run_detection_batched(batch=batch), N)
     out["run_detection_batched"] = {"batch": batch, "pairs": N - 1, "pairs_per_s": round((N - 1) / dt, 1), "ms_per_pair": round(1e3 * dt / (N - 1), 4)}
     p.release()
+    if only_batched:
+        return out
     N1 = n_unbatched + 1
     p, ds = make(N1)
     dt, res_1 = timed(p, ds, p.run_detection, N1)
@@ -421,6 +423,7 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 rehearsal on ONE GPU (tests): process group over gloo, every rank on device 0, records exchanged through torch's "
                          "all-gather of host tensors (RCCL refuses two ranks on one device); the figures it prints are not a scaling measurement")
+    ap.add_argument("--no-api-loop", action="store_true", help="skip the reference-shaped loops leg (Processor.run_detection_batched / run_detection on host frames)")
     ap.add_argument("--no-configs", action="store_true", help="skip the extra BASELINE configuration legs (C2: 1280x720 batch 1; C5 share: 3840x2160, 5 levels, batch 16)")
     args = ap.parse_args()
 
@@ -640,6 +643,12 @@ def main():
                    "C5_share": run_config_leg("C5_share", 3840, 2160, 16, 5, 10, [0, 15], verify=not args.no_verify, ceil=ceil)}
         configs["C5_share"]["note"] = "per-GPU share of BASELINE config 5 (batch 128 across 8 GPUs); its CPU baseline (73 s) is not repeated here"
 
+    # ---- the reference-shaped loops (never `value`): Processor.run_detection_batched / run_detection on host numpy frames ----
+    api_loop = None
+    if rank == 0 and world == 1 and not args.no_api_loop and (W, H, args.levels) == (1920, 1080, 1):
+        ctx.close()                                    # (idempotent) the loops create their own contexts
+        api_loop = api_loop_leg(W, H, batch=B)
+
     failed = False
     if rank == 0:
         pairs = world * B * args.steps
@@ -679,6 +688,9 @@ def main():
             out["video_sequence"] = video
         if roofline:
             out["roofline"] = roofline
+        if api_loop:
+            out["api_loop"] = api_loop
+            failed = failed or not api_loop["batched_and_unbatched_results_identical"]
         if configs:
             out["configs"] = configs
             failed = failed or any(c.get("failed_pairs") for c in configs.values())

@@ -7,6 +7,6 @@ import bench
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 batches = int(sys.argv[2]) if len(sys.argv) > 2 else 6
-out = bench.api_loop_leg(batch=batch, n_batches=batches, staged=True, breakdown=True)
+out = bench.api_loop_leg(batch=batch, n_batches=batches, staged=True)
 for k, v in out.items():
     print(f"{k:40s} {v}")

@@ -61,9 +61,6 @@ for W, H in ((640, 480), (1280, 720), (1920, 1080)):
     ctx.close()
 
 # ---- the reference-shaped loop at 1080p: one Processor.run_detection iteration against process_batch(batch = 1) ----
-import logging
-from mavflow.processor import Processor, SyntheticDataset
-from mavflow.run_config import RunConfig
 
 W, H = 1920, 1080
 print(f"{W}x{H}: Processor loops, per iteration", flush=True)
@@ -81,19 +78,11 @@ for fn, name in ((lambda: ctx.process_batch(prev, nxt, smp, want_flow=False), "p
         t0 = time.perf_counter(); fn(); t.append(time.perf_counter() - t0)
     stats(name, t)
 ctx.close()
-for use_fb, label in ((True, "flow seam = Farneback on the GPU"), (False, "flow seam = host array (.flo-like)")):
-    N = 12
-    for loop in ("run_detection", "run_detection_staged", "run_detection_batched"):
-        ds = SyntheticDataset(W, H, N, use_farneback=use_fb)
-        for i in range(N):
-            ds._pair(i)                                   # frame synthesis is not part of the loop being timed
-        cfg = RunConfig(logging.getLogger("t"), ds, "", False, False, False, True, False, False, "FLOW_FOE_CLUSTERING")
-        p = Processor(cfg)
-        warm = Processor(RunConfig(logging.getLogger("t"), ds, "", False, False, False, True, False, False, "FLOW_FOE_CLUSTERING"))
-        warm.dataset = ds
-        getattr(warm, loop)() if loop != "run_detection_batched" else warm.run_detection_batched(batch=1)
-        t0 = time.perf_counter()
-        getattr(p, loop)() if loop != "run_detection_batched" else p.run_detection_batched(batch=1)
-        dt = (time.perf_counter() - t0) / (N - 1)
-        print(f"  {label:38s} {loop:24s} {dt * 1e3:8.3f} ms per frame", flush=True)
-        ds.release()
+# ---- the reference-shaped loops themselves: bench.py's `api_loop` leg (pre-generated 1080p SyntheticDataset, second run timed) ----
+sys.path.insert(0, ".")
+import bench
+for batch in (64, 1):
+    leg = bench.api_loop_leg(W, H, batch=batch, n_batches=6 if batch > 1 else 64, n_unbatched=96, staged=True, only_batched=(batch == 1))
+    for k, v in leg.items():
+        if k != "workload":
+            print(f"  {k:42s} {v}", flush=True)
