@@ -269,7 +269,7 @@ int mav_download_async(mav_ctx*, void* dst_host, const void* src_dev, size_t byt
  * behind the batch's result download and waits for it when it needs those results. */
 int mav_marker_create(mav_ctx*, void** marker_out);
 int mav_marker_record(mav_ctx*, void* marker);
-int mav_marker_wait(mav_ctx*, void* marker);
+int mav_marker_wait(mav_ctx* /* may be NULL */, void* marker);
 int mav_marker_destroy(mav_ctx* /* may be NULL */, void* marker);
 
 /* Frame decode in front of the path [src/datasets/dataset.py:57,223-230: cv2.VideoCapture over image_%05d.png; src/farneback.py:17-21]:

@@ -35,16 +35,17 @@ class DeviceArray(np.lib.mixins.NDArrayOperatorsMixin):
     first time it is looked at, and -- so that a handle somebody still holds never goes stale -- by its owner right before the
     owner re-uses the memory (`_retire`).  After that it is an ordinary host array behind the same object."""
 
-    __slots__ = ("ctx", "ptr", "shape", "dtype", "_store_dtype", "_host", "__weakref__")
+    __slots__ = ("ctx", "ptr", "shape", "dtype", "_store_dtype", "_host", "_pending", "__weakref__")
 
     def __init__(self, ctx: "_lib.Context", ptr: int, shape, dtype, store_dtype=None):
         self.ctx, self.ptr, self.shape, self.dtype = ctx, int(ptr), tuple(shape), np.dtype(dtype)
         self._store_dtype = np.dtype(store_dtype) if store_dtype is not None else self.dtype
         self._host = None
+        self._pending = None                          # (page-locked block, _Marker): a copy to the host that has been enqueued
 
     @property
     def on_device(self) -> bool:
-        return self._host is None
+        return self._host is None and self._pending is None
 
     @property
     def ndim(self) -> int:
@@ -63,16 +64,28 @@ class DeviceArray(np.lib.mixins.NDArrayOperatorsMixin):
 
     def _materialize(self) -> np.ndarray:
         if self._host is None:
-            if not self.ctx.h:
-                raise _lib.MavflowError("the context that holds this array has been closed")
-            buf = _lib._pinned.empty(self.ctx, self.shape, self._store_dtype)
-            check(self.ctx.lib.mav_memcpy_d2h(self.ctx.h, _lib._ptr(buf), self.ptr, buf.nbytes))
+            if self._pending is not None:             # retired: the copy was enqueued, wait for it (and only for it)
+                buf, marker = self._pending
+                marker.wait()
+                self._pending = None
+            else:
+                if not self.ctx.h:
+                    raise _lib.MavflowError("the context that holds this array has been closed")
+                buf = _lib._pinned.empty(self.ctx, self.shape, self._store_dtype)
+                check(self.ctx.lib.mav_memcpy_d2h(self.ctx.h, _lib._ptr(buf), self.ptr, buf.nbytes))
             self._host = buf.view(self.dtype) if self.dtype != self._store_dtype else buf
         return self._host
 
-    def _retire(self) -> None:
-        """The owner is about to overwrite the device memory: bring the values over first (no-op when already on the host)."""
-        self._materialize()
+    def _retire(self) -> bool:
+        """The owner is about to enqueue work that overwrites the device memory: enqueue the copy to the host AHEAD of it, on the same
+        stream (no host synchronisation: the loop that holds a handle of an older batch must not drain the batch in flight).  The
+        owner records a marker behind the copies of all handles it retires (set through _retired_behind).  True if a copy was enqueued."""
+        if self._host is not None or self._pending is not None:
+            return False
+        buf = _lib._pinned.empty(self.ctx, self.shape, self._store_dtype)
+        check(self.ctx.lib.mav_download_async(self.ctx.h, _lib._ptr(buf), self.ptr, buf.nbytes))
+        self._pending = (buf, None)
+        return True
 
     def __array__(self, dtype=None, copy=None):
         a = self._materialize()
@@ -111,12 +124,38 @@ class DeviceArray(np.lib.mixins.NDArrayOperatorsMixin):
         return f"DeviceArray(shape={self.shape}, dtype={self.dtype}, {where})"
 
 
+class _Marker:
+    """mav_marker_* as an object several handles can share; destroyed with its last holder."""
+
+    def __init__(self, ctx: "_lib.Context"):
+        self.ctx = ctx
+        m = C.c_void_p()
+        check(ctx.lib.mav_marker_create(ctx.h, C.byref(m)))
+        self.m = m
+        check(ctx.lib.mav_marker_record(ctx.h, m))
+
+    def wait(self) -> None:
+        check(self.ctx.lib.mav_marker_wait(self.ctx.h, self.m))
+
+    def __del__(self):
+        try:
+            self.ctx.lib.mav_marker_destroy(None, self.m)
+        except Exception:
+            pass
+
+
 def _retire_all(handles) -> None:
+    """Every handle of `handles` (weak references) that somebody still holds gets its copy to the host enqueued, one marker behind them."""
+    moved = []
     for wr in handles:
         h = wr()
-        if h is not None:
-            h._retire()
+        if h is not None and h._retire():
+            moved.append(h)
     handles.clear()
+    if moved:
+        marker = _Marker(moved[0].ctx)
+        for h in moved:
+            h._pending = (h._pending[0], marker)
 
 
 def _as_frames(frames, H: int, W: int, name: str):
@@ -135,24 +174,58 @@ def _ptr_array(arrays):
     return (C.c_void_p * len(arrays))(*[a.ctypes.data for a in arrays])
 
 
+class _Fence:
+    """One re-recordable marker: "the last enqueued reader of this buffer".  wait() before the host overwrites the buffer through an
+    UNORDERED copy (the copy stream does not wait for the compute stream); a no-op when nothing was recorded or it has long finished."""
+
+    def __init__(self, ctx: "_lib.Context"):
+        self.ctx, self.armed = ctx, False
+        m = C.c_void_p()
+        check(ctx.lib.mav_marker_create(ctx.h, C.byref(m)))
+        self.m = m
+
+    def record(self) -> None:
+        check(self.ctx.lib.mav_marker_record(self.ctx.h, self.m))
+        self.armed = True
+
+    def wait(self) -> None:
+        if self.armed:
+            check(self.ctx.lib.mav_marker_wait(self.ctx.h, self.m))
+            self.armed = False
+
+    def destroy(self) -> None:
+        self.ctx.lib.mav_marker_destroy(None, self.m)
+
+
 class FlowStage:
     """cv2.calcOpticalFlowFarneback(prev, next, ...) (src/farneback.py:76-80) whose result stays where the next stage reads it.
     Frames are (H, W) u8 gray or (H, W, 3) u8 BGR as a capture hands them out; BGR frames are converted on the device
-    (cv2.cvtColor(COLOR_BGR2GRAY), src/farneback.py:21,74 -> mav_bgr2gray_dev)."""
+    (cv2.cvtColor(COLOR_BGR2GRAY), src/farneback.py:21,74 -> mav_bgr2gray_dev).
+
+    Nothing here waits for the work in flight: the gray frames live in a ring of four slots (pairs alternate between slots 0|1 and
+    2|3, a video advances one slot per frame), a new frame is copied into a slot as soon as the LAST flow that read that slot has
+    finished -- two calls ago -- while the previous call's flow and whatever the caller enqueued behind it are still running; the flow
+    fields alternate between two buffers the same way (DeviceArray handles of older calls are brought over before their buffer is
+    re-used)."""
+
+    RING = 4
 
     def __init__(self, ctx: "_lib.Context"):
         self.ctx = ctx
         n0 = ctx.W * ctx.H
-        self._gray = ctx.alloc(2 * n0)                    # the two frames of the pair being computed
-        self._bgr = None                                  # staging of BGR frames (first BGR frame allocates it)
+        self._gray = ctx.alloc(self.RING * n0)
+        self._gray_fence = [_Fence(ctx) for _ in range(self.RING)]
+        self._bgr = None                                  # staging of BGR frames (first BGR frame allocates it): two frames
+        self._bgr_fence = _Fence(ctx)
         self._flow = [ctx.alloc(8 * n0), ctx.alloc(8 * n0)]
         self._handles = [[], []]
         self._turn = 0
+        self._pair_turn = 0
         self._have_prev = False                           # video mode (flow_next): slot of the previous frame
         self._prev_slot = 0
 
-    def _upload(self, frames, slots, ordered: int) -> None:
-        """frames[k] -> gray slot slots[k] (0 / 1) of the pair buffer."""
+    def _upload(self, frames, slots) -> None:
+        """frames[k] -> gray slot slots[k] of the ring."""
         ctx, n0 = self.ctx, self.ctx.W * self.ctx.H
         arrs = []
         for k, f in enumerate(frames):
@@ -160,21 +233,26 @@ class FlowStage:
             if a.dtype != np.uint8 or a.shape[:2] != (ctx.H, ctx.W) or not (a.ndim == 2 or (a.ndim == 3 and a.shape[2] == 3)):
                 raise ValueError(f"frame {k}: expected ({ctx.H}, {ctx.W}) or ({ctx.H}, {ctx.W}, 3) uint8, got {a.shape} {a.dtype}")
             arrs.append(a if a.flags.c_contiguous else np.ascontiguousarray(a))
+        for sl in slots:
+            self._gray_fence[sl].wait()
         gray = [(a, sl) for a, sl in zip(arrs, slots) if a.ndim == 2]
         bgr = [(a, sl) for a, sl in zip(arrs, slots) if a.ndim == 3]
-        if len(gray) == 2 and slots == [0, 1]:
-            check(ctx.lib.mav_upload_gather(ctx.h, self._gray.ptr, _ptr_array([g[0] for g in gray]), 2, n0, ordered))
+        if len(gray) == 2 and slots[1] == slots[0] + 1:
+            check(ctx.lib.mav_upload_gather(ctx.h, self._gray.ptr + slots[0] * n0, _ptr_array([g[0] for g in gray]), 2, n0, 0))
         else:
             for a, sl in gray:
-                check(ctx.lib.mav_upload_gather(ctx.h, self._gray.ptr + sl * n0, _ptr_array([a]), 1, n0, ordered))
+                check(ctx.lib.mav_upload_gather(ctx.h, self._gray.ptr + sl * n0, _ptr_array([a]), 1, n0, 0))
         if bgr:
             if self._bgr is None:
                 self._bgr = ctx.alloc(6 * n0)
+            self._bgr_fence.wait()
             for j, (a, sl) in enumerate(bgr):
-                check(ctx.lib.mav_upload_gather(ctx.h, self._bgr.ptr + j * 3 * n0, _ptr_array([a]), 1, 3 * n0, 1))
+                check(ctx.lib.mav_upload_gather(ctx.h, self._bgr.ptr + j * 3 * n0, _ptr_array([a]), 1, 3 * n0, 0))
         check(ctx.lib.mav_upload_fence(ctx.h))
         for j, (a, sl) in enumerate(bgr):
             check(ctx.lib.mav_bgr2gray_dev(ctx.h, self._bgr.ptr + j * 3 * n0, 1, self._gray.ptr + sl * n0))
+        if bgr:
+            self._bgr_fence.record()
 
     def _flow_into_next_buffer(self, prev_slot: int, next_slot: int) -> DeviceArray:
         ctx, n0 = self.ctx, self.ctx.W * self.ctx.H
@@ -182,6 +260,8 @@ class FlowStage:
         self._turn ^= 1
         _retire_all(self._handles[k])
         ctx.farneback_dev(self._gray.ptr + prev_slot * n0, self._gray.ptr + next_slot * n0, 1, self._flow[k].ptr)
+        for sl in (prev_slot, next_slot):
+            self._gray_fence[sl].record()
         h = DeviceArray(ctx, self._flow[k].ptr, (ctx.H, ctx.W, 2), np.float32)
         self._handles[k].append(weakref.ref(h))
         return h
@@ -190,15 +270,17 @@ class FlowStage:
         """Flow prev -> next as a DeviceArray (H, W, 2) float32.  The handle stays valid: the buffer it points to is re-used by the
         call after the next one, which first brings a still-referenced handle over to the host."""
         self._have_prev = False
-        self._upload([prev, nxt], [0, 1], 1)             # ordered: the previous call's flow kernels may still read the pair buffer
-        return self._flow_into_next_buffer(0, 1)
+        s0 = 2 * self._pair_turn
+        self._pair_turn ^= 1
+        self._upload([prev, nxt], [s0, s0 + 1])
+        return self._flow_into_next_buffer(s0, s0 + 1)
 
     def flow_next(self, frame: np.ndarray) -> Optional[DeviceArray]:
         """Video mode, the reference's Farneback.process() (src/farneback.py:73-81): the flow from the previous frame handed in to this
         one; the previous frame's gray image is still on the device (the class's `prevgray`), so one frame crosses PCIe per step.
         None for the first frame."""
-        slot = self._prev_slot ^ 1 if self._have_prev else 0
-        self._upload([frame], [slot], 1)
+        slot = (self._prev_slot + 1) % self.RING if self._have_prev else 0
+        self._upload([frame], [slot])
         out = self._flow_into_next_buffer(self._prev_slot, slot) if self._have_prev else None
         self._have_prev, self._prev_slot = True, slot
         return out
@@ -206,9 +288,13 @@ class FlowStage:
     def close(self):
         for hs in self._handles:
             _retire_all(hs)
+        if self.ctx.h:
+            self.ctx.sync()                               # the copies of retired handles have landed before the buffers go
         for b in [self._gray, self._bgr] + self._flow:
             if b is not None:
                 b.free()
+        for f in self._gray_fence + [self._bgr_fence]:
+            f.destroy()
 
 
 class _Slot:
@@ -220,7 +306,9 @@ class DetectPipeline:
 
     N_PAIRS = 1000                                        # focus_of_expansion.py:67
 
-    def __init__(self, ctx: "_lib.Context", batch: int, slots: int = 2, keep_flow: bool = False):
+    def __init__(self, ctx: "_lib.Context", batch: int, slots: int = 3, keep_flow: bool = False):
+        """slots = 3: one batch computing, one being enqueued, and the one before still referenced by whoever holds its handles (the
+        loops keep the last finished frame's masks as attributes) -- its buffers are not needed yet, so nothing has to be brought over."""
         if batch > ctx.max_batch:
             raise ValueError(f"batch {batch} exceeds the context's max_batch {ctx.max_batch}")
         self.ctx, self.B, self.keep_flow = ctx, int(batch), bool(keep_flow)

@@ -280,7 +280,10 @@ class Processor:
         calculate_tpr_fpr counts of both masks in ONE enqueue on the context that holds the flow (pipeline.DetectPipeline): a host
         field crosses PCIe once, a device field not at all; a 32-byte record and eight counts come back.  estimate_fixed /
         total_mask are DeviceArray handles (read them and they are host arrays).  Frame 0 takes the reference's float32 path
-        (detector.py:80-81).  The sample coordinates are drawn from np.random exactly where get_FOE_dense draws them."""
+        (detector.py:80-81).  The sample coordinates are drawn from np.random exactly where get_FOE_dense draws them.
+        Software-pipelined by one frame: frame i's FrameResult is filled in (and its JSON written) right after frame i + 1 has been
+        enqueued, so the GPU works on i + 1 while the host finishes i; results, files and their order are those of the plain loop."""
+        pending = None
         while self.is_active():
             i = self.frame_index
             self.dataset.get_frame()
@@ -291,25 +294,39 @@ class Processor:
             if self.flow_uv.dtype != np.float32:
                 # a float64 field is evaluated in float64 from the start by the reference: the fused float32 call would narrow
                 # it, so this frame goes through the float64 kernels (the staged calls)
+                if pending is not None:
+                    self._finish_frame(*pending)
+                    pending = None
                 self._staged_frame(i)
                 continue
             on_dev = isinstance(self.flow_uv, pipeline.DeviceArray) and self.flow_uv.on_device
             pipe = self._pipeline(self.flow_uv.ctx if on_dev else self._own_ctx(1), 1)
+            if pending is not None and pending[0] is not pipe:      # the flow moved to another context: no overlap across contexts
+                self._finish_frame(*pending)
+                pending = None
             kw, skies = self._sky_and_gt([i])
             self.sky_mask = skies[0]
             sky = self.dataset.validate_sky_segment(self.sky_mask, utils.assert_type(self.dataset.get_depth(i)))
-            rand1 = np.zeros((2000, 2), dtype=np.uint32)                 # focus_of_expansion.py:69-71
+            rand1 = np.empty((2000, 2), dtype=np.uint32)                 # focus_of_expansion.py:69-71
             rand1[..., 0] = np.random.randint(0, self.flow_uv.shape[0], 2000)
             rand1[..., 1] = np.random.randint(0, self.flow_uv.shape[1], 2000)
             omega, dt = self._rates(i) if i >= 1 else (np.zeros(3), 1.0)
-            out = pipe.collect(pipe.submit(rand1, flow=self.flow_uv, omega=omega, dt=dt, frame0=[i < 1], **kw))
-            rec = out["results"][0]
-            self.estimate_fixed, self.total_mask = out["mask_fixed"][0], out["mask_dyn"][0]
-            r = self._fill_result(i, (float(rec["foe"][0]), float(rec["foe"][1])), sky, out["counts_fixed"][0], out["counts_dyn"][0])
-            self.detection_boxes[i] = utils.Rectangle.from_box(rec["box"])
-            self._store(i, r)
+            ticket = pipe.submit(rand1, flow=self.flow_uv, omega=omega, dt=dt, frame0=[i < 1], **kw)
+            if pending is not None:
+                self._finish_frame(*pending)
+            pending = (pipe, i, ticket, sky)
             self.frame_index += 1
+        if pending is not None:
+            self._finish_frame(*pending)
         return self.detection_results
+
+    def _finish_frame(self, pipe, i: int, ticket: int, sky) -> None:
+        out = pipe.collect(ticket)
+        rec = out["results"][0]
+        self.estimate_fixed, self.total_mask = out["mask_fixed"][0], out["mask_dyn"][0]
+        r = self._fill_result(i, (float(rec["foe"][0]), float(rec["foe"][1])), sky, out["counts_fixed"][0], out["counts_dyn"][0])
+        self.detection_boxes[i] = utils.Rectangle.from_box(rec["box"])
+        self._store(i, r)
 
     def run_detection_staged(self) -> Dict[int, FrameResult]:
         """The same loop through the reference-named calls one by one (Detector.derotate, get_FOE_dense, the masks): every call
