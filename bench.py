@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- frame-pairs/s of the hot path (frames -> Farneback flow -> FoE -> phi -> masks -> box) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N = 1: this process; N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W          (N = 1: this process; N > 1: one rank per GPU, started by
+                                                            torch.distributed.run or by bench.py's own launcher)
 
 A step is one pass of the whole path over one batch of synthetic 1920x1080 pairs (BASELINE config 3: batch 64 per
 GPU) with the frames already resident in HBM.  Prints ONE JSON line (rank 0).  Multi-GPU: every rank runs its own
@@ -405,6 +406,184 @@ def measured_ceilings(ctx):
             "footprints_MB": [128, 4096]}
 
 
+class RecordExchange:
+    """How the ranks of an N > 1 run meet and what moves the per-pair records between them (ONE all-gather of 32-byte
+    records per batch, nothing else crosses GPUs).
+
+      socket (default)  mavflow.rendezvous: the 128-byte ncclUniqueId, the barriers and the max-over-ranks time travel over a localhost
+                        socket (Python stdlib); the records move through the LIBRARY's communicator on the context's stream
+                        (mav_allgather_results = ncclAllGather), RCCL and the HIP runtime being the ones under /opt/rocm that
+                        libmavflow was built against.  No torch in the process.  If the communicator does not come up on EVERY rank
+                        (agreed through the store), connect() returns False and bench.py re-runs itself on the torch path.
+      torch             torch.distributed (nccl = the RCCL bundled with torch, which the library then shares; falls back to torch's own
+                        all_gather when the library's communicator cannot be opened).
+      --rehearse-on-one-gpu: every rank on device 0; RCCL refuses that, so the records move on the host (through the store, or gloo)."""
+
+    COMM_TIMEOUT_S = 240.0
+
+    def __init__(self, args, rank, world, local_rank):
+        self.mode, self.rehearse = args.rendezvous, args.rehearse_on_one_gpu
+        self.simulate_failure = args.simulate_socket_failure
+        self.rank, self.world, self.local_rank = rank, world, local_rank
+        self.rdzv = self.dist = self.torch = self.mdist = self.comm = None
+        self.t_local = self.t_all = self.host_all = None
+        self.why_not_library = ""
+        self.finished = False
+
+    def init_torch(self):
+        import torch
+        from mavflow import dist as mdist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        self.torch, self.mdist = torch, mdist
+        self.dist, self.rank, self.world, _ = mdist.init_process_group("gloo" if self.rehearse else "nccl")
+        self.tdev = "cpu" if self.rehearse else "cuda"
+
+    def _open_library_comm(self, uid):
+        """mav_comm_init + one all-gather, in a thread the caller can give up on (RCCL's bootstrap blocks for ever when a peer is missing)."""
+        import threading
+        box = {}
+
+        def work():
+            try:
+                comm = self.ctx.comm_init(uid, self.rank, self.world)
+                self.ctx.allgather(comm, self.d_res.ptr, self.nbytes, self.d_all.ptr)
+                self.ctx.sync()
+                box["comm"] = comm
+            except Exception as e:                         # noqa: BLE001 -- reported to the caller
+                box["err"] = e
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        th.join(self.COMM_TIMEOUT_S)
+        if th.is_alive():
+            raise RuntimeError(f"RCCL communicator did not come up within {self.COMM_TIMEOUT_S:.0f} s")
+        if "err" in box:
+            raise box["err"]
+        return box["comm"]
+
+    def connect(self, ctx, d_res, nbytes) -> bool:
+        import numpy as np
+        self.ctx, self.d_res, self.nbytes = ctx, d_res, nbytes
+        self.d_all = ctx.alloc(self.world * nbytes)
+        if self.mode == "torch":
+            torch = self.torch
+            try:
+                if self.rehearse:
+                    raise RuntimeError("rehearsal on one GPU: RCCL cannot hold two ranks on one device")
+                uid = torch.zeros(128, dtype=torch.uint8)
+                if self.rank == 0:
+                    uid = torch.from_numpy(ctx.comm_unique_id().copy())
+                uid = uid.cuda()
+                self.dist.broadcast(uid, src=0)
+                self.comm = self._open_library_comm(uid.cpu().numpy())
+            except Exception as e:                         # noqa: BLE001 -- any failure here must not lose the measurement
+                self.comm, self.why_not_library = None, str(e)
+                self.t_local = torch.empty(nbytes, dtype=torch.uint8, device=self.tdev)
+                self.t_all = torch.empty(self.world * nbytes, dtype=torch.uint8, device=self.tdev)
+            return True
+        from mavflow import rendezvous
+        ok, why = True, ""
+        try:
+            self.rdzv = rendezvous.from_env()
+            uid = self.rdzv.broadcast("uid", ctx.comm_unique_id().tobytes() if self.rank == 0 else None)
+            if len(uid) != 128:
+                raise RuntimeError(f"ncclUniqueId of {len(uid)} bytes")
+            if not self.rehearse:
+                self.comm = self._open_library_comm(np.frombuffer(uid, np.uint8))
+            if self.simulate_failure and self.rank == self.world - 1:
+                raise RuntimeError("simulated failure (--simulate-socket-failure)")
+        except Exception as e:                             # noqa: BLE001
+            ok, why = False, f"{type(e).__name__}: {e}"
+        all_ok = False
+        if self.rdzv is not None:
+            try:
+                flags = self.rdzv.allgather("up", b"1" if ok else why.encode("utf-8", "replace")[:200])
+                all_ok = all(f == b"1" for f in flags)
+                if not all_ok and self.rank == 0:
+                    print(f"[bench] socket rendezvous did not come up on every rank: {[f.decode('utf-8', 'replace') for f in flags]}", file=sys.stderr, flush=True)
+            except Exception as e:                         # noqa: BLE001
+                why = why or str(e)
+        if not all_ok:
+            if self.rank == 0:
+                print(f"[bench] falling back to --rendezvous torch ({why or 'a peer failed'})", file=sys.stderr, flush=True)
+            try:
+                if self.rdzv is not None:
+                    self.rdzv.close()
+            except Exception:                              # noqa: BLE001
+                pass
+            self.d_all.free()
+            return False
+        return True
+
+    def describe(self) -> str:
+        if self.comm is not None:
+            how = "mavflow.rendezvous (localhost socket, no torch; RCCL + HIP runtime from /opt/rocm)" if self.mode == "socket" else "torch.distributed"
+            return f"mav_allgather_results (RCCL ncclAllGather on the context's stream); ncclUniqueId over {how}"
+        if self.mode == "socket":
+            return "rendezvous store all-gather of host records (one-GPU rehearsal: ids only, RCCL cannot hold two ranks on one device)"
+        return f"torch.distributed.all_gather_into_tensor (library communicator unavailable: {self.why_not_library})"
+
+    def exchange(self):
+        import numpy as np
+        if self.finished:                                  # rank 0's post-loop legs re-run the step: the ranks have parted, nothing to exchange
+            return
+        if self.comm is not None:
+            self.ctx.allgather(self.comm, self.d_res.ptr, self.nbytes, self.d_all.ptr)
+        elif self.mode == "socket":
+            self.ctx.sync()
+            self.host_all = self.rdzv.allgather("rec", self.d_res.download(np.uint8, (self.nbytes,)).tobytes())
+        else:
+            torch = self.torch
+            self.ctx.sync()                                # (torch fallback) records -> torch tensor -> all_gather
+            if self.tdev == "cuda":
+                torch.cuda.synchronize()
+            self.t_local.copy_(torch.from_numpy(self.d_res.download(np.uint8, (self.nbytes,))))
+            self.mdist.allgather_records(self.dist, self.t_local, self.t_all)
+            if self.tdev == "cuda":
+                torch.cuda.synchronize()
+
+    def barrier(self):
+        if self.mode == "socket":
+            self.rdzv.barrier("b")
+        else:
+            if self.tdev == "cuda":
+                self.torch.cuda.synchronize()
+            self.dist.barrier()
+            if self.tdev == "cuda":
+                self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, x: float) -> float:
+        if self.mode == "socket":
+            return self.rdzv.allreduce_max("t", x)
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.tdev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gathered(self):
+        import numpy as np
+        if self.comm is not None:
+            return self.d_all.download(np.uint8, (self.world * self.nbytes,))
+        if self.mode == "socket":
+            return np.frombuffer(b"".join(self.host_all), np.uint8)
+        return self.t_all.cpu().numpy()
+
+    def comm_ranks(self):
+        return self.ctx.comm_count(self.comm) if self.comm is not None else None
+
+    def finish(self):
+        self.finished = True
+        if self.comm is not None:
+            self.ctx.comm_destroy(self.comm)
+            self.comm = None
+        if self.rdzv is not None:
+            self.rdzv.close()
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -421,40 +600,42 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="mav_set_option before the run (A/B experiments); repeatable")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
-                    help="N > 1 rehearsal on ONE GPU (tests): process group over gloo, every rank on device 0, records exchanged through torch's "
-                         "all-gather of host tensors (RCCL refuses two ranks on one device); the figures it prints are not a scaling measurement")
+                    help="N > 1 rehearsal on ONE GPU (tests): every rank on device 0, records exchanged on the host -- through the rendezvous "
+                         "store, or torch's all-gather over gloo with --rendezvous torch (RCCL refuses two ranks on one device); the figures it "
+                         "prints are not a scaling measurement")
+    ap.add_argument("--rendezvous", choices=("socket", "torch"), default="socket",
+                    help="how the ranks of an N > 1 run find each other: socket (default) = mavflow.rendezvous, Python stdlib only, RCCL and the "
+                         "HIP runtime from /opt/rocm as libmavflow was built; torch = torch.distributed (its bundled runtime + RCCL).  The socket "
+                         "path falls back to the torch path by itself when it does not come up on every rank")
+    ap.add_argument("--simulate-socket-failure", action="store_true", help="(tests) the last rank reports that its communicator did not come up: every rank "
+                    "must agree to fall back to the torch path")
     ap.add_argument("--no-api-loop", action="store_true", help="skip the reference-shaped loops leg (Processor.run_detection_batched / run_detection on host frames)")
     ap.add_argument("--no-configs", action="store_true", help="skip the extra BASELINE configuration legs (C2: 1280x720 batch 1; C5 share: 3840x2160, 5 levels, batch 16)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # not started by torch.distributed.run: start it (as a child, before anything here touches the GPU) and relay its exit code
-        import socket
-        import subprocess
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        sys.exit(subprocess.call(cmd))
+        # not started by a launcher: start the ranks (as children, before anything here touches the GPU) and relay the exit code.
+        # Default: bench.py's own launcher -- this process hosts the rendezvous store and spawns one rank per GPU, no torch anywhere;
+        # --rendezvous torch: python -m torch.distributed.run, as the driver starts it.
+        if args.rendezvous == "torch":
+            import socket
+            import subprocess
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+                   "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            sys.exit(subprocess.call(cmd))
+        from mavflow import rendezvous
+        sys.exit(rendezvous.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    torch = None
-    if world > 1 or os.environ.get("MAVFLOW_BENCH_DIST") == "1":
-        # torch first: libmavflow then binds to the HIP runtime torch already loaded (same SONAME), one runtime per process
-        import torch
-        from mavflow import dist as mdist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        dist, rank, world, local_rank = mdist.init_process_group("gloo" if args.rehearse_on_one_gpu else "nccl")
-        if args.rehearse_on_one_gpu:
-            local_rank = 0
-    tdev = "cpu" if args.rehearse_on_one_gpu else "cuda"           # where the torch tensors of the process-group collectives live
+    local_rank = 0 if args.rehearse_on_one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1 or os.environ.get("MAVFLOW_BENCH_DIST") == "1"
+    ex = RecordExchange(args, rank, world, local_rank) if distributed else None
+    if ex is not None and ex.mode == "torch":
+        ex.init_torch()                                # torch BEFORE libmavflow: the library then binds to the runtime torch loaded
 
     import numpy as np
     from mavflow import _lib, synth
@@ -480,30 +661,23 @@ def main():
     d_smp = ctx.alloc(samples.nbytes).upload(samples)
     rec = _lib.RESULT_DTYPE.itemsize
     d_res = ctx.alloc(B * rec)                         # this rank's records
-    d_all = ctx.alloc(world * B * rec) if dist is not None else None
     d_mf = ctx.alloc(B * W * H)
     d_md = ctx.alloc(B * W * H)
 
     # the record exchange: RCCL all-gather on the CONTEXT's stream (mav_allgather_results), no host synchronisation inside a step.
-    # The 128-byte ncclUniqueId travels over the process group torch.distributed.run set up.  If the library cannot open its own
-    # communicator the bench falls back to torch's all_gather (two host syncs per step) and says so.
-    comm, exchange = None, "none (1 GPU)"
-    t_local = t_all = None
-    if dist is not None:
-        try:
-            if args.rehearse_on_one_gpu:
-                raise RuntimeError("rehearsal on one GPU: RCCL cannot hold two ranks on one device")
-            uid = torch.zeros(128, dtype=torch.uint8)
-            if rank == 0:
-                uid = torch.from_numpy(ctx.comm_unique_id().copy())
-            uid = uid.cuda()
-            dist.broadcast(uid, src=0)
-            comm = ctx.comm_init(uid.cpu().numpy(), rank, world)
-            exchange = "mav_allgather_results (RCCL ncclAllGather on the context's stream)"
-        except Exception as e:                         # noqa: BLE001 -- any failure here must not lose the measurement
-            comm, exchange = None, f"torch.distributed.all_gather_into_tensor (library communicator unavailable: {e})"
-            t_local = torch.empty(B * rec, dtype=torch.uint8, device=tdev)
-            t_all = torch.empty(world * B * rec, dtype=torch.uint8, device=tdev)
+    if ex is not None:
+        if not ex.connect(ctx, d_res, B * rec):
+            # the torch-free path did not come up on every rank: run the whole measurement again in a CHILD process on the
+            # torch.distributed path (a fresh process: torch's runtime first), relay its output and exit code
+            for d in (d_prev, d_next, d_smp, d_res, d_mf, d_md):
+                d.free()
+            ctx.close()
+            import subprocess
+            argv = [a for a in sys.argv[1:] if a not in ("--rendezvous", "socket", "--simulate-socket-failure")] + ["--rendezvous", "torch"]
+            code = subprocess.call([sys.executable, os.path.abspath(__file__)] + argv)
+            sys.stdout.flush()
+            os._exit(code)                             # (a rank stuck inside RCCL's bootstrap may have left a thread behind)
+    exchange = ex.describe() if ex is not None else "none (1 GPU)"
 
     def run_batch():
         # flow stays in the library's HBM workspace (flow_ptr=None); both threshold masks are written out (1 B/px each),
@@ -512,21 +686,13 @@ def main():
 
     def step():
         run_batch()
-        if comm is not None:
-            ctx.allgather(comm, d_res.ptr, B * rec, d_all.ptr)      # stream-ordered behind the batch, ahead of the next one
-        elif dist is not None:
-            ctx.sync()                                                 # (torch fallback) records -> torch tensor -> all_gather
-            torch.cuda.synchronize()
-            t_local.copy_(torch.from_numpy(d_res.download(np.uint8, (B * rec,))))
-            mdist.allgather_records(dist, t_local, t_all)
-            torch.cuda.synchronize()
+        if ex is not None:
+            ex.exchange()                              # stream-ordered behind the batch, ahead of the next one (library communicator)
 
     def barrier():
         ctx.sync()
-        if dist is not None:
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
+        if ex is not None:
+            ex.barrier()
 
     for _ in range(args.warmup):
         step()
@@ -539,23 +705,25 @@ def main():
     ev_ms = ctx.timer_stop()
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if ex is not None:
+        elapsed = ex.max_over_ranks(elapsed)
 
     # ---- what did the timed loop compute?  (outside the timed region) ----
     verification = None
     res_last = d_res.download(_lib.RESULT_DTYPE, (B,))
-    if comm is not None:                               # the gathered block of this rank must be its own records
-        allrec = d_all.download(_lib.RESULT_DTYPE, (world * B,))
+    gathered_distinct = comm_ranks = None
+    if ex is not None:                                 # the gathered block of this rank must be its own records
+        allrec = ex.gathered().view(_lib.RESULT_DTYPE)
         assert allrec[rank * B:(rank + 1) * B].tobytes() == res_last.tobytes(), "all-gathered records differ from the local ones"
-    elif t_all is not None:                            # torch's all-gather (fallback / one-GPU rehearsal): same check on its block
-        allrec = t_all.cpu().numpy().view(_lib.RESULT_DTYPE)
-        assert allrec[rank * B:(rank + 1) * B].tobytes() == res_last.tobytes(), "all-gathered records differ from the local ones"
-    gathered_distinct = None
-    if dist is not None and world > 1:                 # every rank runs different content (frames rolled by 31 px per rank, other samples)
-        gathered_distinct = len({allrec[r * B:(r + 1) * B].tobytes() for r in range(world)})
+        if world > 1:                                  # every rank runs different content (frames rolled by 31 px per rank, other samples)
+            gathered_distinct = len({allrec[r * B:(r + 1) * B].tobytes() for r in range(world)})
+        comm_ranks = ex.comm_ranks()
+        # the ranks part here: the communicator goes, ranks other than 0 leave; rank 0's post-loop legs (verification, H2D, video,
+        # roofline) hold nobody
+        ex.finish()
+        if rank != 0:
+            ctx.close()
+            return
     if rank == 0 and not args.no_verify:
         verification = verify_last_step(ctx, prev, nxt, samples, res_last, d_mf, d_md, sorted({0, B - 1}), args.levels)
         # ... and EVERY pair of the timed step against the same batch re-run in the plain schedule
@@ -661,7 +829,8 @@ def main():
                "config": {"workload": f"{W}x{H}, batch={B} frame pairs per GPU, Farneback(0.4,{ctx.fb.levels},12,10,8,1.2,0) "
                                       f"+ FoE(1000 pairs) + phi/threshold + box, {len(layers)} pyramid layers",
                           "global_batch": world * B, "parallelism": f"frame-parallel x{world}" + (", all-gather of 32-B records" if world > 1 else ""),
-                          "record_exchange": exchange, "schedule": schedule, "runtime": _lib.runtime_info()},
+                          "record_exchange": exchange, "comm_ranks": comm_ranks, "torch_in_process": "torch" in sys.modules,
+                          "schedule": schedule, "runtime": _lib.runtime_info()},
                "hip_event_ms_per_step": round(ev_ms / args.steps, 3),
                "pipeline_alg_bytes_per_pair": balg,
                "pipeline_alg_GBs": round(value / world * balg / 1e9, 1),
@@ -678,7 +847,7 @@ def main():
         if gathered_distinct is not None:
             out["gathered_rank_blocks_distinct"] = gathered_distinct
         if args.rehearse_on_one_gpu:
-            out["rehearsal"] = f"{world} ranks share ONE GPU, process group over gloo: a functional run of the N > 1 path, not a scaling measurement"
+            out["rehearsal"] = f"{world} ranks share ONE GPU, records exchanged on the host: a functional run of the N > 1 path, not a scaling measurement"
         if world > 1:
             out["scaling_note"] = "per-GPU work fixed (weak); efficiency is the driver's to compute from the per-N values"
         if h2d_ms:
@@ -700,11 +869,6 @@ def main():
         if world == 1 and args.cpu_pairs > 0:
             out["cpu_baseline"] = cpu_baseline(prev, nxt, samples, min(args.cpu_pairs, B), args.levels)
         print(json.dumps(out), flush=True)
-    if comm is not None:
-        ctx.comm_destroy(comm)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
     ctx.close()
     if failed:
         sys.exit(3)

@@ -309,6 +309,7 @@ int mav_membw_probe(mav_ctx*, size_t bytes_per_buffer, int reps, double* gbs);
 int mav_runtime_info(char* buf, size_t cap);
 int mav_comm_unique_id(void* id128 /* 128 bytes out */);
 int mav_comm_init(mav_ctx*, const void* id128, int rank, int nranks, void** comm_out);
+int mav_comm_count(void* comm, int* nranks); /* ncclCommCount: the ranks the communicator really spans */
 int mav_comm_destroy(void* comm);
 int mav_allgather_results(mav_ctx*, void* comm, const void* local_dev, size_t bytes_per_rank, void* all_dev);
 

@@ -2388,6 +2388,15 @@ extern "C" int mav_comm_init(mav_ctx* c, const void* id128, int rank, int nranks
     int rc = ((nccl_init_rank2_t)fn)(comm_out, nranks, id, rank);
     return rc ? fail(MAV_ERR_HIP, "ncclCommInitRank failed: %d", rc) : MAV_OK;
 }
+typedef int (*nccl_comm_count_t)(void*, int*);
+extern "C" int mav_comm_count(void* comm, int* nranks)
+{
+    if (!comm || !nranks) return fail(MAV_ERR_ARG, "mav_comm_count: NULL argument");
+    void* fn;
+    CHK(rccl_sym("ncclCommCount", &fn));
+    int rc = ((nccl_comm_count_t)fn)(comm, nranks);
+    return rc ? fail(MAV_ERR_HIP, "ncclCommCount failed: %d", rc) : MAV_OK;
+}
 extern "C" int mav_comm_destroy(void* comm)
 {
     if (!comm) return MAV_OK;

@@ -52,7 +52,7 @@ EXPORTS = [
     "mav_stage_phi_mask", "mav_last_masks_tpr_fpr", "mav_get_option", "mav_schedule_info", "mav_stage_blur_resize_two_pass",
     "mav_membw_probe", "mav_runtime_info", "mav_upload_async_unordered", "mav_mem_info", "mav_profile_intervals",
     "mav_upload_gather", "mav_download_async", "mav_marker_create", "mav_marker_record", "mav_marker_wait", "mav_marker_destroy",
-    "mav_tpr_fpr_counts_dev", "mav_bgr2gray_dev", "mav_png_unfilter",
+    "mav_tpr_fpr_counts_dev", "mav_bgr2gray_dev", "mav_png_unfilter", "mav_comm_count",
 ]
 
 _lib = None
@@ -147,6 +147,7 @@ def load(path: str | None = None) -> C.CDLL:
     lib.mav_comm_unique_id.argtypes = [vp]
     lib.mav_comm_init.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
     lib.mav_comm_destroy.argtypes = [vp]
+    lib.mav_comm_count.argtypes = [vp, C.POINTER(C.c_int)]
     lib.mav_allgather_results.argtypes = [vp, vp, vp, C.c_size_t, vp]
     lib.mav_stage_blur_resize.argtypes = [vp, vp, C.c_int, vp]
     lib.mav_stage_blur_resize_two_pass.argtypes = [vp, vp, C.c_int, vp]
@@ -630,6 +631,11 @@ class Context:
     def allgather(self, comm, local_ptr, bytes_per_rank: int, all_ptr):
         """ncclAllGather of bytes_per_rank bytes from every rank, enqueued on the context's stream (no host sync)."""
         check(self.lib.mav_allgather_results(self.h, comm, local_ptr, int(bytes_per_rank), all_ptr))
+
+    def comm_count(self, comm) -> int:
+        n = C.c_int()
+        check(self.lib.mav_comm_count(comm, C.byref(n)))
+        return n.value
 
     def comm_destroy(self, comm):
         check(self.lib.mav_comm_destroy(comm))
