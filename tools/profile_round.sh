@@ -36,4 +36,8 @@ python3 tools/untraced_anatomy.py 1920 1080 64 1 > "$out/untraced_anatomy_1080p_
 python3 tools/untraced_anatomy.py 3840 2160 16 5 > "$out/untraced_anatomy_4k_l5_b16.txt" 2>&1 || exit 1
 python3 tools/blur_launches.py "$out"/kt1080/runc/*_kernel_trace.csv > "$out/layer_image_launches_1080p_b64.txt" || exit 1
 python3 tools/blur_launches.py "$out"/kt4k/runc/*_kernel_trace.csv > "$out/layer_image_launches_4k_l5_b16.txt" || exit 1
-find "$out" -name "*kernel_stats.csv" | head
+# what travels back: the summaries.  The raw dispatch traces and counter CSVs (> 64 MB together) stay on the box.
+for t in kt1080 kt4k kt720; do cp "$out"/$t/runc/*_kernel_stats.csv "$out/kernel_stats_$t.csv"; done
+for t in pmc1080 pmc4k pmc720; do cp "$out/$t/summary.txt" "$out/pmc_summary_$t.txt"; done
+rm -rf "$out"/kt1080 "$out"/kt4k "$out"/kt720 "$out"/ktc2 "$out"/pmc1080 "$out"/pmc4k "$out"/pmc720
+du -sh "$out"; ls "$out"
