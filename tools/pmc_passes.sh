@@ -10,7 +10,7 @@ i=0
 while read -r set; do
   [ -z "$set" ] && continue
   i=$((i+1))
-  timeout -k 5 120 rocprofv3 --pmc $set --output-format csv -d "$out/p$i" -- python3 bench.py --steps 1 --warmup 0 --cpu-pairs 0 --no-configs --no-profile --no-verify "$@" > "$out/p$i.log" 2>&1 || echo "pass $i failed: $set"
+  timeout -k 5 120 rocprofv3 --pmc $set --output-format csv -d "$out/p$i" -- python3 bench.py --steps 1 --warmup 0 --cpu-pairs 0 --no-configs --no-profile --no-verify --no-api-loop "$@" > "$out/p$i.log" 2>&1 || echo "pass $i failed: $set"
 done <<'SETS'
 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INSTS_VALU
 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAVES SQ_BUSY_CU_CYCLES
