@@ -801,20 +801,21 @@ def main():
 
     # ---- the other BASELINE configurations one GPU can hold (never `value`; outside the headline's timed region) ----
     configs = None
-    if rank == 0 and world == 1 and not args.no_configs and (W, H, args.levels) == (1920, 1080, 1):
+    extra_legs = rank == 0 and world == 1 and (W, H, args.levels) == (1920, 1080, 1)
+    if extra_legs and not (args.no_configs and args.no_api_loop):
         # the headline's buffers and its whole context (2.9 GB of workspace, 8.5 GB of flow) are released first: the legs then get the
         # memory a stand-alone run of their configuration would get
         for d in (d_prev, d_next, d_mf, d_md, d_smp, d_res):
             d.free()
         ctx.close()
+    if extra_legs and not args.no_configs:
         configs = {"C2": run_config_leg("C2", 1280, 720, 1, 1, 300, [0], verify=not args.no_verify, ceil=ceil),
                    "C5_share": run_config_leg("C5_share", 3840, 2160, 16, 5, 10, [0, 15], verify=not args.no_verify, ceil=ceil)}
         configs["C5_share"]["note"] = "per-GPU share of BASELINE config 5 (batch 128 across 8 GPUs); its CPU baseline (73 s) is not repeated here"
 
     # ---- the reference-shaped loops (never `value`): Processor.run_detection_batched / run_detection on host numpy frames ----
     api_loop = None
-    if rank == 0 and world == 1 and not args.no_api_loop and (W, H, args.levels) == (1920, 1080, 1):
-        ctx.close()                                    # (idempotent) the loops create their own contexts
+    if extra_legs and not args.no_api_loop:
         api_loop = api_loop_leg(W, H, batch=B)
 
     failed = False
