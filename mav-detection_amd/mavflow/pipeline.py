@@ -392,13 +392,6 @@ class DetectPipeline:
         one (H, W, 2) array per pair) -> FoE, masks, box records and, when a ground truth is given, the calculate_tpr_fpr counts of both
         masks.  Returns the ticket for collect().  Nothing is waited for except the slot's own previous batch."""
         ctx, lib = self.ctx, self.ctx.lib
-        si = self._turn
-        self._turn = (self._turn + 1) % len(self.slots)
-        s = self.slots[si]
-        if s.busy:                                            # its previous batch was never collected: finish it before the buffers go
-            check(lib.mav_marker_wait(ctx.h, s.marker))
-            s.busy = False
-        _retire_all(s.handles)
         H, W, n0 = ctx.H, ctx.W, self.n0
         dev_flow = None
         if flow is not None and isinstance(flow, DeviceArray):
@@ -418,20 +411,34 @@ class DetectPipeline:
             fl = [f if f.flags.c_contiguous else np.ascontiguousarray(f) for f in fl]
             n = len(fl)
         elif dev_flow is None:
+            if prev is None or nxt is None:
+                raise ValueError("submit() needs either flow or both prev and nxt")
             p, q = _as_frames(prev, H, W, "prev"), _as_frames(nxt, H, W, "next")
             if len(p) != len(q):
                 raise ValueError("prev and next differ in length")
             n = len(p)
         if not 1 <= n <= self.B:
             raise ValueError(f"{n} pairs outside [1, {self.B}]")
+        smp = np.asarray(samples)
+        if smp.size != n * 4 * self.N_PAIRS:
+            raise ValueError(f"samples: expected {n} x {2 * self.N_PAIRS} x 2 values, got shape {smp.shape}")
+        for name, v, per in (("omega", omega, 3), ("dt", dt, 1), ("frame0", frame0, 1)):
+            if v is not None and np.size(v) != n * per:
+                raise ValueError(f"{name}: expected {n * per} values, got {np.size(v)}")
+
+        # the arguments are in order: take the next slot (only now -- a refused call leaves the pipeline as it was)
+        si = self._turn
+        self._turn = (self._turn + 1) % len(self.slots)
+        s = self.slots[si]
+        if s.busy:                                            # its previous batch was never collected: finish it before the buffers go
+            check(lib.mav_marker_wait(ctx.h, s.marker))
+            s.busy = False
+        _retire_all(s.handles)
         s.n = n
 
         # small per-pair parameters: packed into the slot's page-locked block, one asynchronous copy
         hp = s.h_par
         o, _ = self._par_off["samples"]
-        smp = np.asarray(samples)
-        if smp.size != n * 4 * self.N_PAIRS:
-            raise ValueError(f"samples: expected {n} x {2 * self.N_PAIRS} x 2 values, got shape {smp.shape}")
         hp[o:o + n * 16 * self.N_PAIRS].view(np.uint32)[:] = smp.reshape(-1)
         o_om, _ = self._par_off["omega"]
         o_dt, _ = self._par_off["dt"]

@@ -129,6 +129,15 @@ def test_device_array_handles_survive_the_reuse_of_their_buffers(mav):
             assert np.array_equal(outs[b]["flow"][0], ref[b]["flow"][0]), b
         with pytest.raises(ValueError):
             pipe.collect(0)                                               # already collected
+        # a refused submit (wrong sample count, wrong frame size, no input at all) takes no slot and leaves the pipeline usable
+        turn = pipe._turn
+        for bad in (dict(samples=smp[0][:10], prev=[prev[0]], nxt=[nxt[0]]), dict(samples=smp[0], prev=[prev[0][:-1]], nxt=[nxt[0][:-1]]),
+                    dict(samples=smp[0]), dict(samples=smp[0], prev=[prev[0]], nxt=[nxt[0]], omega=np.zeros(5))):
+            with pytest.raises(ValueError):
+                pipe.submit(**bad)
+        assert pipe._turn == turn
+        again = pipe.collect(pipe.submit(smp[2], prev=[prev[2]], nxt=[nxt[2]]))
+        assert again["results"].tobytes() == ref[2]["results"].tobytes()
         pipe.close()
         stage.close()
 
