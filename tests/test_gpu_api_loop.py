@@ -262,3 +262,38 @@ def test_png_sequence_through_farneback_and_the_flow_provider(mav, fb_oracle, tm
     assert np.array_equal(np.asarray(f01), host.get_flow_uv(0)) and np.array_equal(np.asarray(f12), host.get_flow_uv(1))
     stage.close()
     host.release(); dev.release()
+
+
+@pytest.mark.parametrize("W,H,B", [(322, 243, 3), (250, 190, 2), (641, 359, 4)])
+def test_pipeline_equals_the_host_pointer_call_at_odd_sizes(mav, W, H, B):
+    """Frame sizes that are no multiple of 4 / 16 (unaligned per-pair offsets, the byte path of the count kernel, the general blur): the
+    pipeline's records, masks, counts and flow equal mav_process_batch's, with per-pair sky masks and ground truths, rotation and a
+    frame-0 pair, over more submits than there are slots."""
+    from mavflow import _lib
+    from mavflow.pipeline import DetectPipeline
+    rng = np.random.default_rng(W)
+    prev, nxt = synth.make_batch(W, H, B, distinct=B)
+    smp = np.zeros((B, 2000, 2), np.uint32)
+    smp[..., 0] = rng.integers(0, H, (B, 2000)); smp[..., 1] = rng.integers(0, W, (B, 2000))
+    sky = rng.random((B, H, W)) < 0.05
+    gt = (rng.integers(0, 2, (B, H, W)) * 255).astype(np.uint8)
+    omega = rng.normal(0, 0.2, (B, 3))
+    dt = np.full(B, 1 / 30.0)
+    f0 = [True] + [False] * (B - 1)
+    with _lib.Context(W, H, B) as ctx:
+        ref = ctx.process_batch(prev, nxt, smp, omega=omega, dt=dt, sky=sky, frame0=f0)
+        pipe = DetectPipeline(ctx, B, keep_flow=True)
+        outs = [pipe.collect(pipe.submit(smp, prev=list(prev), nxt=list(nxt), omega=omega, dt=dt, frame0=f0, sky=list(sky), gt=list(gt)))
+                for _ in range(4)]
+        part = pipe.collect(pipe.submit(smp[:1], prev=[prev[0]], nxt=[nxt[0]], omega=omega[:1], dt=dt[:1], frame0=f0[:1], sky=[sky[0]],
+                                        gt_shared=gt[0]))                  # fewer pairs than the pipeline's batch, shared ground truth
+        for o in outs:
+            assert o["results"].tobytes() == ref["results"].tobytes()
+            for k in range(B):
+                assert np.array_equal(o["mask_fixed"][k], ref["mask_fixed"][k]) and np.array_equal(o["mask_dyn"][k], ref["mask_dyn"][k]), k
+                assert np.array_equal(o["flow"][k], ref["flow"][k]), k
+                assert tuple(o["counts_fixed"][k]) == _counts(gt[k], 255 * ref["mask_fixed"][k].astype(np.int64)), k
+                assert tuple(o["counts_dyn"][k]) == _counts(gt[k], 255 * ref["mask_dyn"][k].astype(np.int64)), k
+        assert part["results"].tobytes() == ref["results"][:1].tobytes() and len(part["mask_fixed"]) == 1
+        assert tuple(part["counts_fixed"][0]) == _counts(gt[0], 255 * ref["mask_fixed"][0].astype(np.int64))
+        pipe.close()
