@@ -34,13 +34,18 @@ class SyntheticDataset:
     (use_farneback=True, the seam this build adds) or from the analytic field (the reference's .flo seam)."""
 
     def __init__(self, W: int = 640, H: int = 480, N: int = 6, use_farneback: bool = True, dt: float = 1 / 30.0,
-                 dangle=(0.0, 0.0, 0.0), seed: int = 0, distinct: Optional[int] = None, results_path: Optional[str] = None):
+                 dangle=(0.0, 0.0, 0.0), seed: int = 0, distinct: Optional[int] = None, results_path: Optional[str] = None,
+                 video: bool = False):
         self.capture_size = (W, H)
         self.resolution = np.array([W, H])
         self.constant_segmentation = True                # one segmentation image for all frames (Processor derives it once)
         self.constant_sky_segmentation = True            # ... and one sky mask
         self.N = N
         self.distinct = distinct                         # pair i shows the content of pair i % distinct (long runs from few pictures)
+        # video = True: ONE sequence of frames (synth.make_sequence: a texture under a growing zoom), pair i = (frame i, frame i + 1) as
+        # the SAME array objects -- how a video runs through the reference's loop; the batched loop then uploads and expands every frame once
+        self.video = video
+        self._frames = None
         self.results_path = results_path                 # where Processor writes image_%05d.json (dataset.py: results_path)
         self.sequence = f"synthetic-{seed}"
         self.use_farneback = use_farneback
@@ -55,11 +60,26 @@ class SyntheticDataset:
         self._stage: Optional[pipeline.FlowStage] = None
         self._frame_cursor = 0
 
+    VIDEO_K = 0.004                                      # zoom per frame of the video form (synth.make_sequence)
+
     def _pair(self, i: int):
         if self.distinct:
             i %= self.distinct
         if i not in self._pairs:
-            self._pairs[i] = synth.make_pair(self.capture_size[0], self.capture_size[1], self.seed * 1000 + i)
+            W, H = self.capture_size
+            if self.video:
+                if self._frames is None:
+                    n = (self.distinct or (self.N - 1)) + 1
+                    self._frames = list(synth.make_sequence(W, H, n, seed=self.seed, k=self.VIDEO_K))
+                # frame j is the texture zoomed by j k about c = (0.55 W, 0.45 H): a point seen at x in frame i sits at
+                # x + k (x - c) / (1 - (i + 1) k) in frame i + 1
+                g = self.VIDEO_K / (1.0 - (i + 1) * self.VIDEO_K)
+                truth = np.empty((H, W, 2))
+                truth[..., 0] = (g * (np.arange(W) - 0.55 * W))[None, :]
+                truth[..., 1] = (g * (np.arange(H) - 0.45 * H))[:, None]
+                self._pairs[i] = (self._frames[i], self._frames[i + 1], truth)
+            else:
+                self._pairs[i] = synth.make_pair(W, H, self.seed * 1000 + i)
         return self._pairs[i]
 
     def frame_pair(self, i: int) -> Tuple[np.ndarray, np.ndarray]:

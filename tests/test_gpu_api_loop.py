@@ -297,3 +297,39 @@ def test_pipeline_equals_the_host_pointer_call_at_odd_sizes(mav, W, H, B):
         assert part["results"].tobytes() == ref["results"][:1].tobytes() and len(part["mask_fixed"]) == 1
         assert tuple(part["counts_fixed"][0]) == _counts(gt[0], 255 * ref["mask_fixed"][0].astype(np.int64))
         pipe.close()
+
+
+def test_a_video_dataset_takes_the_frame_sequence_layout_and_the_loops_still_agree(mav, fb_oracle):
+    """SyntheticDataset(video=True): pair i = (frame i, frame i + 1) as the same array objects.  The batched loop hands such batches to
+    the library as ONE run of n + 1 frames (every inner frame uploaded and expanded once); the flow is the pair-by-pair flow bit for bit,
+    so all three loops fill identical FrameResults, and the flow matches the CPU Farneback and the analytic zoom."""
+    from mavflow import pipeline
+    from mavflow.processor import SyntheticDataset
+    W, H, N = 320, 240, 9
+    runs = {}
+    seen = []
+    orig = pipeline.DetectPipeline.submit
+
+    def spy(self, samples, prev=None, nxt=None, **kw):
+        if prev is not None:
+            seen.append(len(prev) > 1 and all(nxt[k] is prev[k + 1] for k in range(len(prev) - 1)))
+        return orig(self, samples, prev=prev, nxt=nxt, **kw)
+    pipeline.DetectPipeline.submit = spy
+    try:
+        for loop in ("run_detection", "run_detection_staged", "run_detection_batched"):
+            ds = SyntheticDataset(W, H, N, use_farneback=True, video=True, dangle=(0.002, 0.001, -0.001))
+            np.random.seed(5)
+            p = _processor(ds)
+            runs[loop] = p.run_detection_batched(batch=4) if loop == "run_detection_batched" else getattr(p, loop)()
+            if loop == "run_detection":
+                flow3 = np.array(ds.get_flow_uv(3))
+                f3, f4, truth = ds._pair(3)
+            p.release()
+    finally:
+        pipeline.DetectPipeline.submit = orig
+    assert seen == [True, True]                                   # both batches of 4 went in as frame sequences
+    for i in range(N - 1):
+        assert vars(runs["run_detection"][i]) == vars(runs["run_detection_staged"][i]) == vars(runs["run_detection_batched"][i]), i
+    check_flow(flow3, fb_oracle.calc(f3, f4), "video pair 3")
+    inner = (slice(20, H - 20), slice(20, W - 20))
+    assert np.abs(flow3[inner] - truth[inner]).mean() < 0.05      # the analytic zoom field (a sanity bound, not a parity bound)

@@ -1,6 +1,6 @@
 """Where a batch of Processor.run_detection_batched goes on the host: wall time inside submit() (gathering the frames into the slot's
 device buffers + enqueueing), inside collect() (waiting for the batch's marker) and in the FrameResult tail, per batch.
-usage: python tools/api_loop_breakdown.py [batch] [batches] [upload_threads] [distinct pairs]"""
+usage: python tools/api_loop_breakdown.py [batch] [batches] [upload_threads] [distinct pairs] [video]"""
 import sys, time, logging
 sys.path.insert(0, "."); sys.path.insert(0, "mav-detection_amd")
 import numpy as np
@@ -12,9 +12,10 @@ batch = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 batches = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 threads = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 distinct = int(sys.argv[4]) if len(sys.argv) > 4 else 8          # distinct pairs the dataset cycles through (8 x 4 MB of frames stay in the host's L3)
+video = len(sys.argv) > 5 and sys.argv[5] == "video"             # pair i = (frame i, frame i + 1) of ONE sequence: frames shared between pairs
 W, H = 1920, 1080
 N = batch * batches + 1
-ds = SyntheticDataset(W, H, N, use_farneback=True, distinct=distinct, dangle=(0.004, -0.002, 0.001))
+ds = SyntheticDataset(W, H, N, use_farneback=True, distinct=distinct, dangle=(0.004, -0.002, 0.001), video=video)
 for i in range(distinct):
     ds._pair(i); ds.get_gt_of(i)
 p = Processor(RunConfig(logging.getLogger("t"), ds, "", False, False, False, True, False, False, "FLOW_FOE_CLUSTERING"))
@@ -54,7 +55,7 @@ t0 = time.perf_counter()
 p.run_detection_batched(batch=batch)
 dt = time.perf_counter() - t0
 ms = lambda v: " ".join(f"{1e3 * x:6.2f}" for x in v)
-print(f"{W}x{H} batch {batch} x {batches}, upload_threads {threads or 'default'}, {distinct} distinct pairs: {(N - 1) / dt:.1f} pairs/s, {1e3 * dt / batches:.2f} ms per batch")
+print(f"{W}x{H} batch {batch} x {batches}, upload_threads {threads or 'default'}, {distinct} distinct pairs{' of one video' if video else ''}: {(N - 1) / dt:.1f} pairs/s, {1e3 * dt / batches:.2f} ms per batch")
 print(f"  submit  per batch (ms): {ms(acc['submit'])}")
 print(f"  collect per batch (ms): {ms(acc['collect'])}")
 for name in ("mav_upload_gather", "mav_process_batch_dev", "mav_tpr_fpr_counts_dev", "mav_upload_async_unordered", "mav_upload_fence", "mav_marker_wait"):
