@@ -499,7 +499,8 @@ class RecordExchange:
         all_ok = False
         if self.rdzv is not None:
             try:
-                flags = self.rdzv.allgather("up", b"1" if ok else why.encode("utf-8", "replace")[:200])
+                # (a peer may sit in RCCL's bootstrap for the whole communicator time-out before it can answer)
+                flags = self.rdzv.allgather("up", b"1" if ok else why.encode("utf-8", "replace")[:200], timeout=self.COMM_TIMEOUT_S + 60.0)
                 all_ok = all(f == b"1" for f in flags)
                 if not all_ok and self.rank == 0:
                     print(f"[bench] socket rendezvous did not come up on every rank: {[f.decode('utf-8', 'replace') for f in flags]}", file=sys.stderr, flush=True)
