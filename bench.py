@@ -330,7 +330,55 @@ def run_config_leg(name, W, H, B, levels, calls, pairs_to_check, verify=True, ce
     out["host_enqueue_ms_per_call"] = round(host_enqueue_ms(ctx, call), 4)
     out["roofline"] = sweep_roofline(ctx, call, B, layers, W, H, levels, out["schedule"], ev_ms / calls, ceil)
     out["host_enqueue_share_of_call"] = round(out["host_enqueue_ms_per_call"] / (ev_ms / calls), 3)
+    if B == 1:
+        out["lanes"] = lanes_leg(ctx, W, H, levels, (d_prev, d_next, d_smp), calls, balg)
+        if not out["lanes"]["records_identical_across_contexts"]:
+            out["failed_pairs"] = out.get("failed_pairs", []) + [-1]
     ctx.close()
+    return out
+
+
+def lanes_leg(ctx0, W, H, levels, inputs, calls, balg):
+    """A STREAM of one-pair calls given to 2 and 3 contexts in turn (each context owns its streams and workspace: consecutive calls on
+    different contexts are independent chains of launches that the GPU interleaves -- mavflow/pipeline.py `auto_lanes`, which the
+    one-frame loop of the API uses).  Throughput of the stream, wall clock over all contexts; the latency of a call stays what
+    `ms_per_call_hip_events` says."""
+    import numpy as np
+    from mavflow import _lib
+    d_prev, d_next, d_smp = inputs
+    n0 = W * H
+    extra = []
+    for _ in range(2):
+        c = _lib.Context(W, H, 1, _lib.fb_defaults(levels=levels))
+        b = [c.alloc(n0), c.alloc(n0), c.alloc(d_smp.nbytes), c.alloc(_lib.RESULT_DTYPE.itemsize), c.alloc(n0), c.alloc(n0)]
+        b[0].upload(d_prev.download(np.uint8, (n0,))); b[1].upload(d_next.download(np.uint8, (n0,))); b[2].upload(d_smp.download(np.uint8, (d_smp.nbytes,)))
+        extra.append((c, b))
+    c0 = (ctx0, [d_prev, d_next, d_smp, ctx0.alloc(_lib.RESULT_DTYPE.itemsize), ctx0.alloc(n0), ctx0.alloc(n0)])
+    out = {"is": "wall-clock ms per pair of a stream of one-pair mav_process_batch_dev calls taken by N contexts in turn (throughput; a call's "
+                 "latency is unchanged); same frames, same results in every context"}
+    recs = []
+    for n in (1, 2, 3):
+        lanes = ([c0] + extra)[:n]
+        for k in range(30):
+            c, b = lanes[k % n]
+            c.process_batch_dev(b[0].ptr, b[1].ptr, b[2].ptr, 1, b[3].ptr, mf_ptr=b[4].ptr, md_ptr=b[5].ptr)
+        for c, _ in lanes:
+            c.sync()
+        reps = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for k in range(calls):
+                c, b = lanes[k % n]
+                c.process_batch_dev(b[0].ptr, b[1].ptr, b[2].ptr, 1, b[3].ptr, mf_ptr=b[4].ptr, md_ptr=b[5].ptr)
+            for c, _ in lanes:
+                c.sync()
+            reps.append(1e3 * (time.perf_counter() - t0) / calls)
+        ms = sorted(reps)[1]
+        out[f"{n}_context" + ("s" if n > 1 else "")] = {"ms_per_pair": round(ms, 4), "frac": round(balg / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4)}
+        recs.append(b"".join(b[3].download(np.uint8, (_lib.RESULT_DTYPE.itemsize,)).tobytes() for _, b in lanes))
+    out["records_identical_across_contexts"] = bool(all(len(set(r[i:i + 32] for i in range(0, len(r), 32))) == 1 for r in recs))
+    for c, b in extra:
+        c.close()
     return out
 
 

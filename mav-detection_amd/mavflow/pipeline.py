@@ -556,3 +556,86 @@ class DetectPipeline:
             rec[1].free()
         self._shared = {}
         self.slots = []
+
+
+# ---- lanes: a stream of SMALL calls spread over several contexts ------------------------------------------------------------------------
+# One pair of a 720p or 1080p video is a chain of ~27 dependent launches of which many fill a fraction of the chip (a coarse-layer sweep
+# at 720p is 144 workgroups on 256 CUs) and all pay a kernel boundary.  A context is single-threaded and owns its streams and workspace;
+# distinct contexts are independent (include/mavflow.h) -- so consecutive one-pair calls given to two or three contexts IN TURN are
+# independent chains the GPU interleaves: one chain's boundaries, tails and latency-bound launches fall into the other's launches.
+# Measured (tools/lanes_probe.py, one pair per call, ms per pair with 1 / 2 / 3 contexts): 1280x720 0.299 / 0.207 / 0.181,
+# 1920x1080 0.540 / 0.466 / 0.485, 640x480 0.207 / 0.124 / 0.105.  Beyond ~200 MB of sweep working set per call the chains fight over
+# the 256 MB Infinity Cache and a second lane loses (a 64-pair batch already keeps two pairs in flight inside its one context).
+def auto_lanes(W: int, H: int, batch: int = 1) -> int:
+    """Contexts a stream of `batch`-pair calls at this frame size is spread over: 3 up to 100 MB of finest-layer sweep working set per
+    call (80 B per pixel and pair), 2 up to 200 MB (one 1080p pair: 166 MB), 1 beyond."""
+    ws = 80 * W * H * batch
+    return 3 if ws <= (100 << 20) else (2 if ws <= (200 << 20) else 1)
+
+
+class LanedFlowStage:
+    """FlowStage over several contexts taken in turn (flow_of); the video form (flow_next) keeps its previous frame on ONE device
+    buffer and therefore stays on the first lane."""
+
+    def __init__(self, ctxs):
+        self.stages = [FlowStage(c) for c in ctxs]
+        self._turn = 0
+
+    @property
+    def lanes(self) -> int:
+        return len(self.stages)
+
+    def flow_of(self, prev: np.ndarray, nxt: np.ndarray) -> DeviceArray:
+        st = self.stages[self._turn]
+        self._turn = (self._turn + 1) % len(self.stages)
+        return st.flow_of(prev, nxt)
+
+    def flow_next(self, frame: np.ndarray) -> Optional[DeviceArray]:
+        return self.stages[0].flow_next(frame)
+
+    def close(self):
+        for st in self.stages:
+            st.close()
+
+
+class LanedPipeline:
+    """DetectPipeline over several contexts.  A batch whose flow is a DeviceArray goes to the lane (context) that holds it; anything
+    else takes the lanes in turn.  Tickets are (lane, slot); collect them in submission order.  `depth` = how many submitted batches a
+    loop should keep uncollected so that every lane has work (the number of lanes)."""
+
+    def __init__(self, ctxs, batch: int, **kw):
+        self.pipes = [DetectPipeline(c, batch, **kw) for c in ctxs]
+        self._turn = 0
+
+    @property
+    def depth(self) -> int:
+        return len(self.pipes)
+
+    @property
+    def ctxs(self):
+        return [p.ctx for p in self.pipes]
+
+    def set_params(self, foe_params=None, thr_params=None) -> None:
+        for p in self.pipes:
+            if foe_params is not None:
+                p.foe_params = foe_params
+            if thr_params is not None:
+                p.thr_params = thr_params
+
+    def submit(self, samples, flow=None, **kw):
+        if isinstance(flow, DeviceArray) and flow.on_device:
+            lane = next((k for k, p in enumerate(self.pipes) if p.ctx is flow.ctx), None)
+            if lane is None:
+                raise ValueError("a DeviceArray flow must live on one of this pipeline's contexts")
+        else:
+            lane = self._turn
+            self._turn = (self._turn + 1) % len(self.pipes)
+        return lane, self.pipes[lane].submit(samples, flow=flow, **kw)
+
+    def collect(self, ticket) -> dict:
+        lane, t = ticket
+        return self.pipes[lane].collect(t)
+
+    def close(self):
+        for p in self.pipes:
+            p.close()

@@ -35,7 +35,7 @@ class SyntheticDataset:
 
     def __init__(self, W: int = 640, H: int = 480, N: int = 6, use_farneback: bool = True, dt: float = 1 / 30.0,
                  dangle=(0.0, 0.0, 0.0), seed: int = 0, distinct: Optional[int] = None, results_path: Optional[str] = None,
-                 video: bool = False):
+                 video: bool = False, lanes: Optional[int] = None):
         self.capture_size = (W, H)
         self.resolution = np.array([W, H])
         self.constant_segmentation = True                # one segmentation image for all frames (Processor derives it once)
@@ -46,6 +46,7 @@ class SyntheticDataset:
         # the SAME array objects -- how a video runs through the reference's loop; the batched loop then uploads and expands every frame once
         self.video = video
         self._frames = None
+        self.lanes = lanes                               # contexts the Farneback seam takes in turn (None: pipeline.auto_lanes for one pair)
         self.results_path = results_path                 # where Processor writes image_%05d.json (dataset.py: results_path)
         self.sequence = f"synthetic-{seed}"
         self.use_farneback = use_farneback
@@ -56,8 +57,8 @@ class SyntheticDataset:
         self._gt32 = {}
         self._bgr = {}
         self._seg = self._sky = self._depth = None       # the constant images are built once, like files read once
-        self._ctx: Optional[_lib.Context] = None
-        self._stage: Optional[pipeline.FlowStage] = None
+        self._ctxs = []
+        self._stage: Optional[pipeline.LanedFlowStage] = None
         self._frame_cursor = 0
 
     VIDEO_K = 0.004                                      # zoom per frame of the video form (synth.make_sequence)
@@ -99,9 +100,11 @@ class SyntheticDataset:
         f0, f1, truth = self._pair(i)
         if not self.use_farneback:
             return self.get_gt_of(i)
-        if self._ctx is None:
-            self._ctx = _lib.Context(self.capture_size[0], self.capture_size[1], 1)
-            self._stage = pipeline.FlowStage(self._ctx)
+        if self._stage is None:
+            W, H = self.capture_size
+            n = self.lanes or pipeline.auto_lanes(W, H, 1)
+            self._ctxs = [_lib.Context(W, H, 1) for _ in range(n)]
+            self._stage = pipeline.LanedFlowStage(self._ctxs)
         return self._stage.flow_of(f0, f1)
 
     def get_gt_of(self, i: int) -> np.ndarray:
@@ -144,10 +147,11 @@ class SyntheticDataset:
         return self.dangle
 
     def release(self) -> None:
-        if self._ctx is not None:
+        if self._stage is not None:
             self._stage.close()
-            self._ctx.close()
-            self._ctx = self._stage = None
+            for c in self._ctxs:
+                c.close()
+            self._ctxs, self._stage = [], None
 
 
 class Processor:
@@ -171,8 +175,8 @@ class Processor:
         self._derot, self._derot_frame = None, 0
         # {results_path}/image_{i:05d}.json per frame (processor.py:83-84); the reference takes the directory from its dataset
         self.results_path = results_path if results_path is not None else getattr(self.dataset, "results_path", None)
-        self._ctx: Optional[_lib.Context] = None        # this loop's own context (never the helpers' shared, evictable ones)
-        self._pipes: Dict[Tuple[int, int], pipeline.DetectPipeline] = {}
+        self._ctxs = []                                 # this loop's own contexts (never the helpers' shared, evictable ones)
+        self._pipes = {}
         self._seg_val = None
         self._center = None
 
@@ -180,23 +184,37 @@ class Processor:
         return self.frame_index < self.dataset.N - 1 and not self.is_exiting
 
     # -- device plumbing --------------------------------------------------------------------------------------------------------
-    def _pipeline(self, ctx: "_lib.Context", batch: int) -> "pipeline.DetectPipeline":
-        key = (id(ctx), batch)
+    def _pipeline(self, ctxs, batch: int) -> "pipeline.LanedPipeline":
+        """The (cached) pipeline over these contexts for `batch` pairs per submit."""
+        key = (tuple(id(c) for c in ctxs), batch)
         pipe = self._pipes.get(key)
-        if pipe is None or pipe.ctx is not ctx or not ctx.h:
-            pipe = pipeline.DetectPipeline(ctx, batch)
-            pipe.foe_params = self.focus_of_expansion._foe_params(1000)
+        if pipe is None or any(a is not b or not b.h for a, b in zip(pipe.ctxs, ctxs)):
+            if pipe is not None:
+                pipe.close()
+            pipe = pipeline.LanedPipeline(ctxs, batch)
+            pipe.set_params(foe_params=self.focus_of_expansion._foe_params(1000))
             self._pipes[key] = pipe
         return pipe
 
-    def _own_ctx(self, batch: int = 1) -> "_lib.Context":
+    def _own_ctxs(self, batch: int = 1, lanes: int = 1):
+        """This loop's own contexts (never the helpers' shared, evictable ones): `lanes` of them, each for `batch` pairs."""
         W, H = self.dataset.capture_size
-        if self._ctx is None or not self._ctx.h or self._ctx.max_batch < batch or (self._ctx.W, self._ctx.H) != (W, H):
+        ok = len(self._ctxs) >= lanes and all(c.h and c.max_batch >= batch and (c.W, c.H) == (W, H) for c in self._ctxs[:lanes])
+        if not ok:
             self._close_pipes()
-            if self._ctx is not None:
-                self._ctx.close()
-            self._ctx = _lib.Context(W, H, batch)
-        return self._ctx
+            for c in self._ctxs:
+                c.close()
+            self._ctxs = [_lib.Context(W, H, batch) for _ in range(lanes)]
+        return self._ctxs[:lanes]
+
+    def _flow_ctxs(self, flow) -> list:
+        """The contexts a device-resident flow seam works on: every lane of the stage that produced this handle when the dataset shows
+        it (SyntheticDataset, FarnebackFlowProvider: attribute _stage), else the handle's own context."""
+        for holder in (self.dataset, getattr(self.dataset, "_flow", None)):
+            st = getattr(holder, "_stage", None)
+            if isinstance(st, pipeline.LanedFlowStage) and any(s.ctx is flow.ctx for s in st.stages):
+                return [s.ctx for s in st.stages]
+        return [flow.ctx]
 
     def _close_pipes(self) -> None:
         for pipe in self._pipes.values():
@@ -301,9 +319,17 @@ class Processor:
         field crosses PCIe once, a device field not at all; a 32-byte record and eight counts come back.  estimate_fixed /
         total_mask are DeviceArray handles (read them and they are host arrays).  Frame 0 takes the reference's float32 path
         (detector.py:80-81).  The sample coordinates are drawn from np.random exactly where get_FOE_dense draws them.
-        Software-pipelined by one frame: frame i's FrameResult is filled in (and its JSON written) right after frame i + 1 has been
-        enqueued, so the GPU works on i + 1 while the host finishes i; results, files and their order are those of the plain loop."""
-        pending = None
+        Software-pipelined: frame i's FrameResult is filled in (and its JSON written) after the following frames -- as many as the
+        pipeline has lanes (pipeline.auto_lanes: 2 - 3 contexts taken in turn for frames up to 1080p, whose one-pair chains of launches
+        then interleave on the GPU) -- have been enqueued; results, files and their order are those of the plain loop."""
+        from collections import deque
+        pending = deque()
+
+        def finish(n_keep: int) -> None:
+            while len(pending) > n_keep:
+                self._finish_frame(*pending.popleft())
+
+        pipe = None
         while self.is_active():
             i = self.frame_index
             self.dataset.get_frame()
@@ -314,16 +340,16 @@ class Processor:
             if self.flow_uv.dtype != np.float32:
                 # a float64 field is evaluated in float64 from the start by the reference: the fused float32 call would narrow
                 # it, so this frame goes through the float64 kernels (the staged calls)
-                if pending is not None:
-                    self._finish_frame(*pending)
-                    pending = None
+                finish(0)
                 self._staged_frame(i)
                 continue
             on_dev = isinstance(self.flow_uv, pipeline.DeviceArray) and self.flow_uv.on_device
-            pipe = self._pipeline(self.flow_uv.ctx if on_dev else self._own_ctx(1), 1)
-            if pending is not None and pending[0] is not pipe:      # the flow moved to another context: no overlap across contexts
-                self._finish_frame(*pending)
-                pending = None
+            W, H = self.dataset.capture_size
+            ctxs = self._flow_ctxs(self.flow_uv) if on_dev else self._own_ctxs(1, pipeline.auto_lanes(W, H, 1))
+            now = self._pipeline(ctxs, 1)
+            if now is not pipe:                                         # the flow moved to other contexts: drain the old pipeline first
+                finish(0)
+                pipe = now
             kw, skies = self._sky_and_gt([i])
             self.sky_mask = skies[0]
             sky = self.dataset.validate_sky_segment(self.sky_mask, utils.assert_type(self.dataset.get_depth(i)))
@@ -332,15 +358,13 @@ class Processor:
             rand1[..., 1] = np.random.randint(0, self.flow_uv.shape[1], 2000)
             omega, dt = self._rates(i) if i >= 1 else (np.zeros(3), 1.0)
             ticket = pipe.submit(rand1, flow=self.flow_uv, omega=omega, dt=dt, frame0=[i < 1], **kw)
-            if pending is not None:
-                self._finish_frame(*pending)
-            pending = (pipe, i, ticket, sky)
+            pending.append((pipe, i, ticket, sky))
+            finish(pipe.depth)
             self.frame_index += 1
-        if pending is not None:
-            self._finish_frame(*pending)
+        finish(0)
         return self.detection_results
 
-    def _finish_frame(self, pipe, i: int, ticket: int, sky) -> None:
+    def _finish_frame(self, pipe, i: int, ticket, sky) -> None:
         out = pipe.collect(ticket)
         rec = out["results"][0]
         self.estimate_fixed, self.total_mask = out["mask_fixed"][0], out["mask_dyn"][0]
@@ -379,10 +403,13 @@ class Processor:
         FoE -> masks -> box -> counts), two batches in flight: while batch k computes, batch k + 1's frames are gathered from the
         dataset's arrays and cross PCIe, and batch k - 1's FrameResults are filled in.  Needs a dataset that hands out frame pairs
         (frame_pair(i)).  The sample coordinates are drawn per frame in frame order, as get_FOE_dense draws them."""
+        from collections import deque
         W, H = self.dataset.capture_size
         idx = list(range(self.frame_index, self.dataset.N - 1))
-        pipe = self._pipeline(self._own_ctx(batch), batch)
-        pending = None
+        # small batches (one pair at 720p / 1080p ...) are spread over 2 - 3 contexts taken in turn; a big batch keeps two pairs in
+        # flight inside its one context
+        pipe = self._pipeline(self._own_ctxs(batch, pipeline.auto_lanes(W, H, batch)), batch)
+        pending = deque()
         for b0 in range(0, len(idx), batch):
             ids = idx[b0:b0 + batch]
             pairs = [self.dataset.frame_pair(i) for i in ids]
@@ -398,11 +425,11 @@ class Processor:
             sky_scores = [self.dataset.validate_sky_segment(sk, utils.assert_type(self.dataset.get_depth(i))) for i, sk in zip(ids, skies)]
             ticket = pipe.submit(samples, prev=[p[0] for p in pairs], nxt=[p[1] for p in pairs], omega=omega, dt=dts,
                                  frame0=[i < 1 for i in ids], **kw)
-            if pending is not None:
-                self._finish_batch(pipe, *pending)
-            pending = (ids, ticket, sky_scores)
-        if pending is not None:
-            self._finish_batch(pipe, *pending)
+            pending.append((ids, ticket, sky_scores))
+            while len(pending) > pipe.depth:
+                self._finish_batch(pipe, *pending.popleft())
+        while pending:
+            self._finish_batch(pipe, *pending.popleft())
         self.frame_index = self.dataset.N - 1
         return self.detection_results
 
@@ -417,7 +444,7 @@ class Processor:
 
     def release(self) -> None:
         self._close_pipes()
-        if self._ctx is not None:
-            self._ctx.close()
-            self._ctx = None
+        for c in self._ctxs:
+            c.close()
+        self._ctxs = []
         self.dataset.release()

@@ -333,3 +333,53 @@ def test_a_video_dataset_takes_the_frame_sequence_layout_and_the_loops_still_agr
     check_flow(flow3, fb_oracle.calc(f3, f4), "video pair 3")
     inner = (slice(20, H - 20), slice(20, W - 20))
     assert np.abs(flow3[inner] - truth[inner]).mean() < 0.05      # the analytic zoom field (a sanity bound, not a parity bound)
+
+
+def test_lanes_give_the_single_context_results(mav):
+    """A stream of one-pair calls spread over three contexts taken in turn (pipeline.LanedFlowStage / LanedPipeline, what the one-frame
+    loop uses up to 1080p): flow, records, masks and counts of every pair equal the single-context results; a DeviceArray flow is
+    followed to the lane that holds it; the tickets collect in submission order with `depth` batches outstanding."""
+    from collections import deque
+    from mavflow import _lib
+    from mavflow.pipeline import LanedFlowStage, LanedPipeline, auto_lanes
+    assert (auto_lanes(1280, 720), auto_lanes(1920, 1080), auto_lanes(3840, 2160), auto_lanes(1920, 1080, 64), auto_lanes(640, 480, 2)) == (3, 2, 1, 1, 3)
+    W, H, n = 320, 240, 7
+    prev, nxt = synth.make_batch(W, H, n, distinct=n)
+    smp = np.stack([synth.foe_samples(W, H, b) for b in range(n)])
+    gt = np.zeros((H, W), np.uint8)
+    gt[60:84, 80:104] = 255
+    with _lib.Context(W, H, 1) as c0:
+        ref = [c0.process_batch(prev[b:b + 1], nxt[b:b + 1], smp[b:b + 1]) for b in range(n)]
+    ctxs = [_lib.Context(W, H, 1) for _ in range(3)]
+    stage, pipe = LanedFlowStage(ctxs), LanedPipeline(ctxs, 1)
+    assert stage.lanes == 3 and pipe.depth == 3
+    pending, outs, flows = deque(), [], []
+    for b in range(n):
+        f = stage.flow_of(prev[b], nxt[b])
+        assert f.ctx is ctxs[b % 3]
+        flows.append(f)
+        pending.append(pipe.submit(smp[b], flow=f, gt_shared=gt))
+        assert pending[-1][0] == b % 3                                  # the ticket's lane is the one that holds the flow
+        while len(pending) > pipe.depth:
+            outs.append(pipe.collect(pending.popleft()))
+    while pending:
+        outs.append(pipe.collect(pending.popleft()))
+    for b in range(n):
+        assert outs[b]["results"].tobytes() == ref[b]["results"].tobytes(), b
+        assert np.array_equal(outs[b]["mask_fixed"][0], ref[b]["mask_fixed"][0]) and np.array_equal(outs[b]["mask_dyn"][0], ref[b]["mask_dyn"][0]), b
+        assert np.array_equal(np.asarray(flows[b]), ref[b]["flow"][0]), b
+        assert tuple(outs[b]["counts_fixed"][0]) == _counts(gt, 255 * ref[b]["mask_fixed"][0].astype(np.int64)), b
+    # frames (no flow handle) take the lanes in turn
+    t = [pipe.submit(smp[b], prev=[prev[b]], nxt=[nxt[b]]) for b in range(3)]
+    assert [x[0] for x in t] == [0, 1, 2]
+    for b in range(3):
+        assert pipe.collect(t[b])["results"].tobytes() == ref[b]["results"].tobytes()
+    other = _lib.Context(W, H, 1)
+    with pytest.raises(ValueError):
+        from mavflow.pipeline import FlowStage
+        st = FlowStage(other)
+        pipe.submit(smp[0], flow=st.flow_of(prev[0], nxt[0]))               # a flow on a context the pipeline does not span
+    st.close(); other.close()
+    pipe.close(); stage.close()
+    for c in ctxs:
+        c.close()

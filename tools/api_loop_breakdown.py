@@ -20,7 +20,7 @@ for i in range(distinct):
     ds._pair(i); ds.get_gt_of(i)
 p = Processor(RunConfig(logging.getLogger("t"), ds, "", False, False, False, True, False, False, "FLOW_FOE_CLUSTERING"))
 if threads:
-    p._own_ctx(batch).set_option("upload_threads", threads)
+    [c.set_option("upload_threads", threads) for c in p._own_ctxs(batch, 1)]
 acc = {"submit": [], "collect": [], "total": []}
 orig_submit, orig_collect = pipeline.DetectPipeline.submit, pipeline.DetectPipeline.collect
 
