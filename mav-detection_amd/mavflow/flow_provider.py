@@ -41,9 +41,11 @@ class FarnebackFlowProvider:
     changing; the fields are bit-identical to the one-pair calls."""
 
     def __init__(self, get_gray: Callable[[int], np.ndarray], width: int, height: int, img_path: Optional[str] = None,
-                 write_flo: bool = False, window: int = 1, n_frames: Optional[int] = None, on_device: bool = False) -> None:
+                 write_flo: bool = False, window: int = 1, n_frames: Optional[int] = None, on_device: bool = False,
+                 lanes: Optional[int] = None) -> None:
         """on_device (window = 1): get_flow_uv returns a pipeline.DeviceArray -- the field stays on the GPU until somebody reads it,
-        which Processor.run_detection never does (BGR frames are converted there too); off by default: a host float32 array."""
+        which Processor.run_detection never does (BGR frames are converted there too); off by default: a host float32 array.
+        lanes: contexts the on-device seam takes in turn (None: pipeline.auto_lanes -- 3 up to ~720p, 2 at 1080p, 1 beyond)."""
         from . import _lib
         self.get_gray, self.img_path, self.write_flo = get_gray, img_path, write_flo
         if window < 1 or (window > 1 and n_frames is None):
@@ -52,11 +54,14 @@ class FarnebackFlowProvider:
         self.ctx = _lib.Context(width, height, self.window)
         self._cache: dict = {}
         self._stage = None
+        self._lane_ctxs = []
         if on_device:
             if self.window != 1:
                 raise ValueError("on_device needs window = 1")
             from . import pipeline
-            self._stage = pipeline.FlowStage(self.ctx)
+            n = lanes or pipeline.auto_lanes(width, height, 1)
+            self._lane_ctxs = [_lib.Context(width, height, 1) for _ in range(n - 1)]
+            self._stage = pipeline.LanedFlowStage([self.ctx] + self._lane_ctxs)
         if write_flo and not img_path:
             raise ValueError("write_flo needs img_path")
 
@@ -104,4 +109,6 @@ class FarnebackFlowProvider:
     def release(self) -> None:
         if self._stage is not None:
             self._stage.close()
+        for c in self._lane_ctxs:
+            c.close()
         self.ctx.close()
