@@ -344,8 +344,9 @@ class Processor:
                 self._staged_frame(i)
                 continue
             on_dev = isinstance(self.flow_uv, pipeline.DeviceArray) and self.flow_uv.on_device
-            W, H = self.dataset.capture_size
-            ctxs = self._flow_ctxs(self.flow_uv) if on_dev else self._own_ctxs(1, pipeline.auto_lanes(W, H, 1))
+            # (a host flow field -- the .flo seam -- is a 3-launch chain behind a 16.6 MB upload at 1080p: PCIe-bound, one lane; measured
+            # 0.43 ms per frame with one context, 0.47 - 0.53 with two)
+            ctxs = self._flow_ctxs(self.flow_uv) if on_dev else self._own_ctxs(1, 1)
             now = self._pipeline(ctxs, 1)
             if now is not pipe:                                         # the flow moved to other contexts: drain the old pipeline first
                 finish(0)
