@@ -426,8 +426,9 @@ def api_loop_leg(W=1920, H=1080, batch=64, n_batches=12, n_unbatched=96, staged=
     N1 = n_unbatched + 1
     p, ds = make(N1)
     dt, res_1 = timed(p, ds, p.run_detection, N1)
+    from mavflow import pipeline
     out["run_detection"] = {"flow_seam": "Farneback on the GPU (DeviceArray)", "frames": N1 - 1, "ms_per_frame": round(1e3 * dt / (N1 - 1), 4),
-                            "pairs_per_s": round((N1 - 1) / dt, 1)}
+                            "pairs_per_s": round((N1 - 1) / dt, 1), "lanes": pipeline.auto_lanes(W, H, 1)}
     same = all(vars(res_1[i]) == vars(res_b[i]) for i in range(min(N1, N) - 1))
     out["batched_and_unbatched_results_identical"] = bool(same)
     p.release()
