@@ -36,8 +36,9 @@ WORKER = textwrap.dedent("""
         assert (allrec["foe"][:, 0] == 0.5 * np.arange(world * B)).all()
     lo, hi = shard(512, rank, world)
     assert hi - lo == 512 // world
+    c.barrier("align")                                    # everybody is here (process start-up skew is behind us) ...
     if rank == world - 1:
-        time.sleep(0.3)                                   # a straggler: the barrier must hold the others
+        time.sleep(0.4)                                   # ... then one rank straggles: the barrier must hold the others
     t0 = time.monotonic()
     c.barrier("b")
     waited = time.monotonic() - t0
