@@ -383,3 +383,26 @@ def test_lanes_give_the_single_context_results(mav):
     pipe.close(); stage.close()
     for c in ctxs:
         c.close()
+
+
+def test_host_flow_seam_fast_loop_equals_the_staged_loop(mav):
+    """Dataset.get_flow_uv returning a HOST float32 field (what a .flo file gives): the fast loop uploads it once per frame through the
+    gather (one lane: the chain is PCIe-bound) and must fill the FrameResults the reference-named calls fill; the masks it leaves behind
+    are the staged loop's."""
+    from mavflow.processor import SyntheticDataset
+    W, H, N = 320, 240, 6
+    res = {}
+    for loop in ("run_detection", "run_detection_staged"):
+        ds = SyntheticDataset(W, H, N, use_farneback=False, dangle=(0.003, -0.001, 0.002))
+        np.random.seed(17)
+        p = _processor(ds)
+        out = getattr(p, loop)()
+        res[loop] = (out, np.array(p.estimate_fixed), np.array(p.total_mask))
+        if loop == "run_detection":
+            assert len(p._ctxs) == 1 and not isinstance(p.flow_uv, type(p.estimate_fixed))     # a host array in, one lane
+        p.release()
+    a, b = res["run_detection"], res["run_detection_staged"]
+    assert sorted(a[0]) == list(range(N - 1))
+    for i in range(N - 1):
+        assert vars(a[0][i]) == vars(b[0][i]), i
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
