@@ -848,12 +848,15 @@ static int ensure_stager(mav_ctx* c)
     c->stager = s;
     return MAV_OK;
 }
-static bool host_ptr_is_page_locked(const void* p)
+// 1: page-locked host memory (send it from where it is); 0: plain host memory (stage it); -1: device memory (a caller's mistake)
+static int host_ptr_kind(const void* p)
 {
     hipPointerAttribute_t a;
     memset(&a, 0, sizeof(a));
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // plain malloc'd memory: an error or "unregistered"
-    return a.type == hipMemoryTypeHost;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return 0; }   // plain malloc'd memory: an error or "unregistered"
+    if (a.type == hipMemoryTypeHost) return 1;
+    if (a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeArray) return -1;
+    return a.type == hipMemoryTypeManaged ? 1 : 0;
 }
 
 extern "C" int mav_upload_gather(mav_ctx* c, void* dst_dev, const void* const* src_host, int count, size_t bytes_each, int ordered)
@@ -861,6 +864,11 @@ extern "C" int mav_upload_gather(mav_ctx* c, void* dst_dev, const void* const* s
     if (!c || !dst_dev || !src_host || count < 1) return fail(MAV_ERR_ARG, "mav_upload_gather: NULL argument or count < 1");
     for (int i = 0; i < count; i++) if (!src_host[i]) return fail(MAV_ERR_ARG, "mav_upload_gather: source %d is NULL", i);
     if (!bytes_each) return MAV_OK;
+    std::vector<int> kind(count);
+    for (int i = 0; i < count; i++) {
+        kind[i] = (i > 0 && src_host[i] == src_host[i - 1]) ? kind[i - 1] : host_ptr_kind(src_host[i]);
+        if (kind[i] < 0) return fail(MAV_ERR_ARG, "mav_upload_gather: source %d is a device pointer (host arrays expected)", i);
+    }
     HIPCHK(hipSetDevice(c->device));
     if (ordered) {               // as mav_upload_async: behind everything enqueued on the compute stream so far
         HIPCHK(hipEventRecord(c->compute_mark, c->stream));
@@ -891,7 +899,7 @@ extern "C" int mav_upload_gather(mav_ctx* c, void* dst_dev, const void* const* s
     for (int i = 0; i < count; i++) {
         const char* src = (const char*)src_host[i];
         const size_t dev_off = (size_t)i * bytes_each;
-        if (host_ptr_is_page_locked(src)) {    // straight from where it is; whatever was staged before it goes first (keeps nothing waiting)
+        if (kind[i] == 1) {                    // straight from where it is; whatever was staged before it goes first (keeps nothing waiting)
             if (s) CHK(flush());
             HIPCHK(hipMemcpyAsync(dst + dev_off, src, bytes_each, hipMemcpyHostToDevice, c->copy_stream));
             continue;

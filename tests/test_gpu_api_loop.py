@@ -196,6 +196,9 @@ def test_upload_gather_pageable_pinned_replicated_and_large(mav):
             _lib.check(ctx.lib.mav_upload_gather(ctx.h, None, _ptr_array([np.zeros(4, np.uint8)]), 1, 4, 0))
         with pytest.raises(_lib.MavflowError):
             ctx.set_option("upload_threads", 2)                             # the staging threads exist already
+        dev = ctx.alloc(64)
+        with pytest.raises(ValueError):                                     # a device pointer among the sources is refused, not read as host memory
+            _lib.check(ctx.lib.mav_upload_gather(ctx.h, ctx.alloc(64).ptr, (C.c_void_p * 1)(dev.ptr), 1, 64, 0))
 
 
 @pytest.mark.parametrize("W,H", [(64, 48), (37, 29)])
