@@ -113,6 +113,11 @@ int mav_device_count(void);       /* <= 0 when no GPU is visible */
  *   "phi_screen"       0: every pixel of the phi / threshold stage takes the exact path (default 1: float32 screen in front of it)
  *   "phi_yloop"        16-row blocks per workgroup of the phi kernel (0 = automatic)
  *   "upload_threads"   host threads that stage pageable sources for mav_upload_gather (default 4, the caller included; until its first call)
+ *   "inline_uploads"   default 0; 1 = mav_upload_async / _unordered / mav_upload_gather enqueue their copies on the context's COMPUTE stream
+ *                      and mav_upload_fence is a no-op: the context then owns one stream (its copy stream and its second compute stream are
+ *                      created by the first call that needs them), i.e. one of the runtime's few hardware queues.  For contexts that take a
+ *                      stream of small calls in turn with other contexts ("lanes", mavflow/pipeline.py): streams beyond the runtime's queue
+ *                      pool share queues, and lanes that share one do not overlap
  * None of them changes a result bit (tests/test_gpu_flow.py, tests/test_gpu_screen.py). */
 int mav_set_option(mav_ctx*, const char* name, long value);
 int mav_get_option(mav_ctx*, const char* name, long* value);

@@ -285,6 +285,7 @@ struct mav_ctx {
     hipEvent_t copy_done = nullptr, compute_mark = nullptr;
     struct Stager* stager = nullptr;     // mav_upload_gather: page-locked ring + worker threads (created by its first call)
     int upload_threads = 4;              // option "upload_threads"
+    bool inline_uploads = false;         // option "inline_uploads": uploads go on the compute stream (no copy stream, no cross-stream events)
     const float* last_flow = nullptr;    // where the latest farneback / process_batch call wrote its flow (mav_last_flow_dev)
     const uint8_t *last_mf = nullptr, *last_md = nullptr;   // masks of the latest host-pointer detection call, still in their
     int last_mask_batch = 0;                                // staging blocks (mav_last_masks_tpr_fpr)
@@ -495,6 +496,23 @@ static int ensure_workspace(mav_ctx* c)
     return c->ws_ready ? MAV_OK : alloc_group(c, c->group);
 }
 
+static int ensure_copy_stream(mav_ctx* c)
+{
+    if (c->copy_stream) return MAV_OK;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    for (hipEvent_t* e : {&c->copy_done, &c->compute_mark}) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    return MAV_OK;
+}
+static int ensure_pair_stream(mav_ctx* c)
+{
+    if (c->pair_stream) return MAV_OK;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamCreateWithFlags(&c->pair_stream, hipStreamNonBlocking));
+    for (hipEvent_t* e : {&c->pif_fork, &c->pif_join}) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    return MAV_OK;
+}
+
 static int sync_all_streams(mav_ctx* c)
 {
     for (hipStream_t st : {c->stream, c->pair_stream})
@@ -559,9 +577,11 @@ extern "C" int mav_create(mav_ctx** out, int device, int W, int H, int max_batch
     c->device = device; c->W = W; c->H = H; c->max_batch = max_batch; c->fb = fb;
     auto bail = [&](int code) { mav_destroy(c); return code; };
 #define HIPB(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fail(e_ == hipErrorOutOfMemory ? MAV_ERR_OOM : MAV_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); return bail(e_ == hipErrorOutOfMemory ? MAV_ERR_OOM : MAV_ERR_HIP); } } while (0)
-    for (hipStream_t* st : {&c->stream, &c->copy_stream, &c->pair_stream}) HIPB(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
-    for (hipEvent_t* e : {&c->copy_done, &c->compute_mark, &c->pif_fork, &c->pif_join})
-        HIPB(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    // The compute stream now; the copy stream (overlapped uploads) and the pair stream (two pairs in flight) with their events when a
+    // call first needs them (ensure_copy_stream / ensure_pair_stream): a context that serves one-pair calls as one of several LANES
+    // (mavflow/pipeline.py) then owns exactly one stream, i.e. one hardware queue of the runtime's small pool -- streams beyond the
+    // pool's size share queues, and two lanes whose streams share one do not overlap at all.
+    HIPB(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPB(hipEventCreate(&c->t0));
     HIPB(hipEventCreate(&c->t1));
     if (!prepare_poly(fb.poly_n, fb.poly_sigma, &c->pc)) { fail(MAV_ERR_ARG, "poly_sigma %g gives a singular moment matrix", fb.poly_sigma); return bail(MAV_ERR_ARG); }
@@ -665,6 +685,7 @@ extern "C" int mav_get_option(mav_ctx* c, const char* name, long* value)
 {
     if (!c || !name || !value) return fail(MAV_ERR_ARG, "mav_get_option: NULL argument");
     if (!strcmp(name, "upload_threads")) { *value = c->upload_threads; return MAV_OK; }
+    if (!strcmp(name, "inline_uploads")) { *value = c->inline_uploads; return MAV_OK; }
     long tmp;
     if (!option_slot(c, name, &tmp)) return fail(MAV_ERR_ARG, "unknown option '%s'", name);
     *value = tmp;
@@ -673,6 +694,14 @@ extern "C" int mav_get_option(mav_ctx* c, const char* name, long* value)
 extern "C" int mav_set_option(mav_ctx* c, const char* name, long value)
 {
     if (!c || !name) return fail(MAV_ERR_ARG, "mav_set_option: NULL argument");
+    if (!strcmp(name, "inline_uploads")) {      // not part of the launch schedule either
+        if (value < 0 || value > 1) return fail(MAV_ERR_ARG, "option 'inline_uploads' must be 0 or 1, got %ld", value);
+        HIPCHK(hipSetDevice(c->device));
+        if (c->copy_stream) HIPCHK(hipStreamSynchronize(c->copy_stream));      // nothing of the old mode is left in flight
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->inline_uploads = value != 0;
+        return MAV_OK;
+    }
     if (!strcmp(name, "upload_threads")) {      // host side of mav_upload_gather; not part of the launch schedule (mav_schedule_info)
         if (value < 1 || value > 64) return fail(MAV_ERR_ARG, "option 'upload_threads' must be in [1, 64], got %ld", value);
         if (c->stager) return fail(MAV_ERR_STATE, "upload_threads must be set before the first mav_upload_gather call");
@@ -808,6 +837,8 @@ extern "C" int mav_host_free(mav_ctx* c, void* p)
 extern "C" int mav_upload_async(mav_ctx* c, void* dst_dev, const void* src_host, size_t bytes)
 {
     if (!c || !dst_dev || !src_host) return fail(MAV_ERR_ARG, "mav_upload_async: NULL argument");
+    if (c->inline_uploads) { HIPCHK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->stream)); return MAV_OK; }
+    CHK(ensure_copy_stream(c));
     // the copy may overwrite a buffer that work already enqueued on the compute stream still reads (the previous user of a
     // double-buffered set): order the copy stream behind everything enqueued there so far
     HIPCHK(hipEventRecord(c->compute_mark, c->stream));
@@ -818,6 +849,8 @@ extern "C" int mav_upload_async(mav_ctx* c, void* dst_dev, const void* src_host,
 extern "C" int mav_upload_async_unordered(mav_ctx* c, void* dst_dev, const void* src_host, size_t bytes)
 {
     if (!c || !dst_dev || !src_host) return fail(MAV_ERR_ARG, "mav_upload_async_unordered: NULL argument");
+    if (c->inline_uploads) { HIPCHK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->stream)); return MAV_OK; }
+    CHK(ensure_copy_stream(c));
     // no wait for the compute stream: the caller vouches that nothing enqueued so far touches dst_dev (a buffer set that work
     // already enqueued does not use), so the copy overlaps that work whatever the order of the two calls
     HIPCHK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->copy_stream));
@@ -826,6 +859,7 @@ extern "C" int mav_upload_async_unordered(mav_ctx* c, void* dst_dev, const void*
 extern "C" int mav_upload_fence(mav_ctx* c)
 {
     if (!c) return fail(MAV_ERR_ARG, "mav_upload_fence: NULL context");
+    if (c->inline_uploads || !c->copy_stream) return MAV_OK;          // the copies ARE on the compute stream / there have been none
     HIPCHK(hipEventRecord(c->copy_done, c->copy_stream));
     HIPCHK(hipStreamWaitEvent(c->stream, c->copy_done, 0));   // work enqueued after this call sees the uploaded bytes
     return MAV_OK;
@@ -870,7 +904,9 @@ extern "C" int mav_upload_gather(mav_ctx* c, void* dst_dev, const void* const* s
         if (kind[i] < 0) return fail(MAV_ERR_ARG, "mav_upload_gather: source %d is a device pointer (host arrays expected)", i);
     }
     HIPCHK(hipSetDevice(c->device));
-    if (ordered) {               // as mav_upload_async: behind everything enqueued on the compute stream so far
+    if (!c->inline_uploads) CHK(ensure_copy_stream(c));
+    const hipStream_t cs = c->inline_uploads ? c->stream : c->copy_stream;
+    if (ordered && !c->inline_uploads) {   // as mav_upload_async: behind everything enqueued on the compute stream so far
         HIPCHK(hipEventRecord(c->compute_mark, c->stream));
         HIPCHK(hipStreamWaitEvent(c->copy_stream, c->compute_mark, 0));
     }
@@ -883,8 +919,8 @@ extern "C" int mav_upload_gather(mav_ctx* c, void* dst_dev, const void* const* s
         const unsigned k = s->next_chunk % Stager::NCHUNK;
         s->copy_all();
         s->segs.clear();
-        HIPCHK(hipMemcpyAsync(dst + chunk_dst, s->chunk[k], fill, hipMemcpyHostToDevice, c->copy_stream));
-        HIPCHK(hipEventRecord(s->sent[k], c->copy_stream));
+        HIPCHK(hipMemcpyAsync(dst + chunk_dst, s->chunk[k], fill, hipMemcpyHostToDevice, cs));
+        HIPCHK(hipEventRecord(s->sent[k], cs));
         s->in_flight[k] = true;
         s->next_chunk++;
         fill = 0;
@@ -901,7 +937,7 @@ extern "C" int mav_upload_gather(mav_ctx* c, void* dst_dev, const void* const* s
         const size_t dev_off = (size_t)i * bytes_each;
         if (kind[i] == 1) {                    // straight from where it is; whatever was staged before it goes first (keeps nothing waiting)
             if (s) CHK(flush());
-            HIPCHK(hipMemcpyAsync(dst + dev_off, src, bytes_each, hipMemcpyHostToDevice, c->copy_stream));
+            HIPCHK(hipMemcpyAsync(dst + dev_off, src, bytes_each, hipMemcpyHostToDevice, cs));
             continue;
         }
         if (!s) { CHK(ensure_stager(c)); s = c->stager; }
@@ -1265,6 +1301,7 @@ static int layer_sweeps(mav_ctx* c, hipStream_t st, int k, int g, const float* r
     const int kid = k == 0 ? K_ITER : K_ITER_COARSE;
     const int T = blur_iter_tile_rows(l.h);
     if (p.mode == SW_TWO_PAIRS) {
+        CHK(ensure_pair_stream(c));
         HIPCHK(hipEventRecord(c->pif_fork, st));
         HIPCHK(hipStreamWaitEvent(c->pair_stream, c->pif_fork, 0));
         for (int s0 = 0; s0 < g; s0++) {
@@ -1288,6 +1325,7 @@ static int layer_sweeps(mav_ctx* c, hipStream_t st, int k, int g, const float* r
         return MAV_OK;
     }
     if (p.mode == SW_COARSE_TWO) {
+        CHK(ensure_pair_stream(c));
         HIPCHK(hipEventRecord(c->pif_fork, st));
         HIPCHK(hipStreamWaitEvent(c->pair_stream, c->pif_fork, 0));
         int idx = 0;

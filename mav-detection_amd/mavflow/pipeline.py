@@ -573,11 +573,25 @@ def auto_lanes(W: int, H: int, batch: int = 1) -> int:
     return 3 if ws <= (100 << 20) else (2 if ws <= (200 << 20) else 1)
 
 
+def _one_stream_per_lane(ctxs) -> None:
+    """Several lanes: every context keeps ALL its work -- uploads included -- on its one compute stream (option "inline_uploads"; the copy
+    and pair streams of a context are only created when first used).  The HIP runtime maps streams onto a small pool of hardware queues
+    (4 by default): streams beyond it share queues, two lanes whose streams share a queue do not overlap at all, and a lane whose copy
+    stream sits on another lane's queue waits for that lane's kernels.  Measured with two lanes at 1080p, the one-frame loop: 0.48 ms
+    per frame when the runtime happened to spread the six streams well, 0.61 (= one lane) after an earlier context had shifted the
+    assignment, 0.79 with an eight-queue pool; one stream per lane makes it 0.47 - 0.48 in every order (profiles/r05/lanes_probe.txt).
+    A single lane keeps its copy stream: there the upload of frame i + 1 overlaps the chain of frame i."""
+    if len(ctxs) > 1:
+        for c in ctxs:
+            c.set_option("inline_uploads", 1)
+
+
 class LanedFlowStage:
     """FlowStage over several contexts taken in turn (flow_of); the video form (flow_next) keeps its previous frame on ONE device
     buffer and therefore stays on the first lane."""
 
     def __init__(self, ctxs):
+        _one_stream_per_lane(ctxs)
         self.stages = [FlowStage(c) for c in ctxs]
         self._turn = 0
 
@@ -604,6 +618,7 @@ class LanedPipeline:
     loop should keep uncollected so that every lane has work (the number of lanes)."""
 
     def __init__(self, ctxs, batch: int, **kw):
+        _one_stream_per_lane(ctxs)
         self.pipes = [DetectPipeline(c, batch, **kw) for c in ctxs]
         self._turn = 0
 
