@@ -564,7 +564,7 @@ class DetectPipeline:
 # distinct contexts are independent (include/mavflow.h) -- so consecutive one-pair calls given to two or three contexts IN TURN are
 # independent chains the GPU interleaves: one chain's boundaries, tails and latency-bound launches fall into the other's launches.
 # Measured (tools/lanes_probe.py, one pair per call, ms per pair with 1 / 2 / 3 contexts): 1280x720 0.299 / 0.207 / 0.181,
-# 1920x1080 0.540 / 0.466 / 0.485, 640x480 0.207 / 0.124 / 0.105.  Beyond ~200 MB of sweep working set per call the chains fight over
+# 1920x1080 0.523 / 0.429 / 0.458, 640x480 0.207 / 0.124 / 0.101 (one stream per lane: _one_stream_per_lane).  Beyond ~200 MB of sweep working set per call the chains fight over
 # the 256 MB Infinity Cache and a second lane loses (a 64-pair batch already keeps two pairs in flight inside its one context).
 def auto_lanes(W: int, H: int, batch: int = 1) -> int:
     """Contexts a stream of `batch`-pair calls at this frame size is spread over: 3 up to 100 MB of finest-layer sweep working set per
