@@ -409,3 +409,29 @@ def test_host_flow_seam_fast_loop_equals_the_staged_loop(mav):
     for i in range(N - 1):
         assert vars(a[0][i]) == vars(b[0][i]), i
     assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+def test_loops_agree_over_random_shapes_lanes_and_batches(mav):
+    """A small fuzz of the three loops: frame sizes that are no multiple of 4 / 16, 1 - 3 lanes, batch sizes that divide the run or not,
+    with and without rotation, Farneback or host-flow seam.  FrameResults of the fast loops == the staged loop's, frame by frame."""
+    from mavflow.processor import SyntheticDataset
+    rng = np.random.default_rng(2025)
+    for case in range(6):
+        W, H = int(rng.integers(100, 200)) * (2 if case % 2 else 1), int(rng.integers(90, 160))
+        N = int(rng.integers(4, 9))
+        lanes = int(rng.integers(1, 4))
+        batch = int(rng.integers(1, 5))
+        use_fb = case % 3 != 2
+        dangle = tuple(rng.normal(0, 0.003, 3)) if case % 2 else (0.0, 0.0, 0.0)
+        runs = {}
+        for loop in ("run_detection_staged", "run_detection") + (("run_detection_batched",) if use_fb else ()):
+            ds = SyntheticDataset(W, H, N, use_farneback=use_fb, dangle=dangle, lanes=lanes, seed=case)
+            np.random.seed(100 + case)
+            p = _processor(ds)
+            runs[loop] = p.run_detection_batched(batch=batch) if loop == "run_detection_batched" else getattr(p, loop)()
+            p.release()
+        base = runs.pop("run_detection_staged")
+        assert sorted(base) == list(range(N - 1)), (case, W, H)
+        for loop, res in runs.items():
+            for i in range(N - 1):
+                assert vars(res[i]) == vars(base[i]), (case, W, H, N, lanes, batch, loop, i)
