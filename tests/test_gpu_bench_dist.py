@@ -142,3 +142,26 @@ def test_bench_two_ranks_rehearsed_through_the_socket_rendezvous(launcher):
     assert d["verified_pairs"] == [0, 7] and d["verification"]["all_pairs_equal_plain_schedule"]
     assert d["config"]["record_exchange"].startswith("rendezvous store all-gather") and d["config"]["torch_in_process"] is False
     assert abs(d["value"] - 16 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"] + 0.5
+
+
+@pytest.mark.parametrize("launcher", ["own", "torch.distributed.run"])
+def test_two_ranks_agree_to_fall_back_to_the_torch_path(launcher):
+    """One of two ranks reports that its communicator did not come up (--simulate-socket-failure): BOTH ranks must leave the socket path,
+    re-run in child processes on the torch.distributed path (under the launcher's process group, or, with bench.py's own launcher, the
+    MASTER_PORT it reserved for exactly this) and rank 0's child prints the one line."""
+    import socket
+    tail = ["--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8", "--rehearse-on-one-gpu", "--simulate-socket-failure", "--no-profile",
+            "--cpu-pairs", "0", "--no-configs", "--no-api-loop"]
+    if launcher == "own":
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + tail
+    else:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+               str(port), os.path.join(ROOT, "bench.py")] + tail
+    p = subprocess.run(cmd, env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=600)
+    d = _line(p)
+    assert "falling back to --rendezvous torch" in p.stderr
+    assert d["n_gpus"] == 2 and d["gathered_rank_blocks_distinct"] == 2 and d["config"]["torch_in_process"] is True
+    assert d["config"]["record_exchange"].startswith("torch.distributed.all_gather_into_tensor") and d["verified_pairs"] == [0, 7]
