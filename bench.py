@@ -437,6 +437,19 @@ def api_loop_leg(W=1920, H=1080, batch=64, n_batches=12, n_unbatched=96, staged=
     out["run_detection_host_flow"] = {"flow_seam": "float32 host array per frame (what a .flo file gives)", "frames": N1 - 1,
                                       "ms_per_frame": round(1e3 * dt / (N1 - 1), 4)}
     p.release()
+    if (W, H) == (1920, 1080):
+        # BASELINE config 2's shape through the same door: the one-frame loop at 1280x720 (three lanes)
+        W2, H2 = 1280, 720
+        ds = SyntheticDataset(W2, H2, N1, use_farneback=True, distinct=8, dangle=(0.004, -0.002, 0.001))
+        for i in range(8):
+            ds._pair(i); ds.get_gt_of(i)
+        for _ in range(N1):
+            ds.get_frame()
+        p = Processor(RunConfig(logging.getLogger("bench"), ds, "", False, False, False, True, False, False, "FLOW_FOE_CLUSTERING"))
+        dt, _ = timed(p, ds, p.run_detection, N1)
+        out["run_detection_1280x720"] = {"flow_seam": "Farneback on the GPU (DeviceArray)", "frames": N1 - 1, "ms_per_frame": round(1e3 * dt / (N1 - 1), 4),
+                                         "lanes": pipeline.auto_lanes(W2, H2, 1)}
+        p.release()
     if staged:
         Ns = 13
         p, ds = make(Ns)

@@ -4,7 +4,7 @@ sys.path.insert(0, "."); sys.path.insert(0, "mav-detection_amd")
 import numpy as np
 from mavflow.processor import Processor, SyntheticDataset
 from mavflow.run_config import RunConfig
-W, H, N = 1920, 1080, 201
+W, H, N = (int(sys.argv[1]), int(sys.argv[2]), 201) if len(sys.argv) > 2 else (1920, 1080, 201)
 ds = SyntheticDataset(W, H, N, use_farneback=True, distinct=8, dangle=(0.004, -0.002, 0.001))
 for i in range(8):
     ds._pair(i); ds.get_gt_of(i)
