@@ -184,7 +184,12 @@ def from_env(timeout: float = 120.0) -> Client:
         store = Store()
         host, port = store.start()
         tmp = f"{path}.{os.getpid()}"
-        with open(tmp, "w") as f:
+        try:
+            os.unlink(tmp)
+        except OSError:
+            pass
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)   # ours, fresh, no symlink followed
+        with os.fdopen(fd, "w") as f:
             f.write(f"{host}:{port}")
         os.replace(tmp, path)                             # atomic: a reader never sees a half-written file
         c = Client(host, port, rank, world, timeout, store=store)
@@ -199,8 +204,12 @@ def from_env(timeout: float = 120.0) -> Client:
     deadline = time.monotonic() + timeout
     while True:
         try:
+            if os.lstat(path).st_uid != os.getuid():      # the temporary directory is shared: only a file of our own is believed
+                raise OSError("rendezvous port file is not ours")
             with open(path) as f:
                 host, port = f.read().strip().rsplit(":", 1)
+            if host != "127.0.0.1":
+                raise ValueError("rendezvous store must be on localhost")
             break
         except (OSError, ValueError):
             if time.monotonic() > deadline:
