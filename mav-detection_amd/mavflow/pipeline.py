@@ -115,7 +115,7 @@ class DeviceArray(np.lib.mixins.NDArrayOperatorsMixin):
         return iter(self._materialize())
 
     def __getattr__(self, name):                      # .sum(), .astype(), .view(), .T ... : whatever ndarray offers
-        if name.startswith("__"):
+        if name.startswith("__") or name in DeviceArray.__slots__:   # (a slot that is not set yet must not send us into _materialize)
             raise AttributeError(name)
         return getattr(self._materialize(), name)
 
@@ -581,9 +581,8 @@ def _one_stream_per_lane(ctxs) -> None:
     per frame when the runtime happened to spread the six streams well, 0.61 (= one lane) after an earlier context had shifted the
     assignment, 0.79 with an eight-queue pool; one stream per lane makes it 0.47 - 0.48 in every order (profiles/r05/lanes_probe.txt).
     A single lane keeps its copy stream: there the upload of frame i + 1 overlaps the chain of frame i."""
-    if len(ctxs) > 1:
-        for c in ctxs:
-            c.set_option("inline_uploads", 1)
+    for c in ctxs:
+        c.set_option("inline_uploads", 1 if len(ctxs) > 1 else 0)
 
 
 class LanedFlowStage:
