@@ -214,7 +214,12 @@ class Processor:
             st = getattr(holder, "_stage", None)
             if isinstance(st, pipeline.LanedFlowStage) and any(s.ctx is flow.ctx for s in st.stages):
                 return [s.ctx for s in st.stages]
-        return [flow.ctx]
+        # a seam that does not show its stage: the contexts its handles have come from so far (a seam that takes two or three contexts
+        # in turn is recognised within its first frames; the pipeline is then rebuilt once over all of them)
+        self._lane_seen = [c for c in getattr(self, "_lane_seen", []) if c.h]
+        if not any(c is flow.ctx for c in self._lane_seen):
+            self._lane_seen.append(flow.ctx)
+        return list(self._lane_seen)
 
     def _close_pipes(self) -> None:
         for pipe in self._pipes.values():

@@ -435,3 +435,37 @@ def test_loops_agree_over_random_shapes_lanes_and_batches(mav):
         for loop, res in runs.items():
             for i in range(N - 1):
                 assert vars(res[i]) == vars(base[i]), (case, W, H, N, lanes, batch, loop, i)
+
+
+def test_a_seam_that_hides_its_lanes_is_followed_anyway(mav):
+    """get_flow_uv handing out DeviceArrays from two contexts in turn without showing the stage (any user-written seam): the loop
+    collects the contexts it has seen, spans its pipeline over them, and fills the FrameResults of the staged loop."""
+    from mavflow import _lib, pipeline
+    from mavflow.processor import SyntheticDataset
+    W, H, N = 256, 192, 7
+
+    class Hidden(SyntheticDataset):
+        def get_flow_uv(self, i):
+            if not hasattr(self, "_mine"):
+                self._mine_ctxs = [_lib.Context(W, H, 1) for _ in range(2)]
+                self._mine = [pipeline.FlowStage(c) for c in self._mine_ctxs]
+            f0, f1, _ = self._pair(i)
+            return self._mine[i % 2].flow_of(f0, f1)
+
+        def release(self):
+            for st in getattr(self, "_mine", []):
+                st.close()
+            for c in getattr(self, "_mine_ctxs", []):
+                c.close()
+
+    res = {}
+    for loop in ("run_detection", "run_detection_staged"):
+        ds = Hidden(W, H, N, use_farneback=True, dangle=(0.001, 0.002, -0.001))
+        np.random.seed(9)
+        p = _processor(ds)
+        res[loop] = getattr(p, loop)()
+        if loop == "run_detection":
+            assert len(p._lane_seen) == 2
+        p.release()
+    for i in range(N - 1):
+        assert vars(res["run_detection"][i]) == vars(res["run_detection_staged"][i]), i
