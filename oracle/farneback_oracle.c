@@ -351,49 +351,61 @@ void fbo_update_matrices(const float* R0, const float* R1, const float* flow, in
     fbo_update_matrices_rows(R0, R1, flow, w, h, M, 0, h);
 }
 
-/* FarnebackUpdateFlow_Blur (A.6): one sweep; M is rewritten in row stripes behind the sweep when update != 0 */
-void fbo_blur_iter(const float* R0, const float* R1, float* flow_, float* matM, int width, int height,
-                   int block_size, int update_matrices)
+/* FarnebackUpdateFlow_Blur (A.6): one sweep; M is rewritten in row stripes behind the sweep when update != 0.
+ * sys (nullable, h x w x 7 doubles) receives, per pixel, the scaled 2x2 system it was solved from and the flow the sweep
+ * replaced: (g11, g12, g22, h1, h2, u_before, v_before) -- the checker's view of how well conditioned a pixel is and of
+ * how far the iteration still moves there (oracle/tolerances.py); OpenCV has no such output.
+ * acc_float != 0 is NOT OpenCV: the same sweep with every window sum and the solve rounded to float32 after each operation
+ * (OpenCV accumulates them in double).  It exists to measure how far the restatement's OWN result moves under float32 rounding
+ * of its sums -- the numerically unstable pixels of oracle/tolerances.py -- and is never the expected value of a test. */
+#define RND(v) (acc_float ? (double)(float)(v) : (double)(v))
+void fbo_blur_iter_ex(const float* R0, const float* R1, float* flow_, float* matM, int width, int height,
+                      int block_size, int update_matrices, double* sys, int acc_float)
 {
     int m = block_size / 2;
     int y0 = 0, y1;
     int min_update_stripe = (1 << 10) / width > block_size ? (1 << 10) / width : block_size;
-    double scale = 1. / (block_size * block_size);
+    double scale = RND(1. / (block_size * block_size));
     double* _vsum = (double*)malloc(sizeof(double) * (size_t)(width + m * 2 + 2) * 5);
     double* vsum = _vsum + (m + 1) * 5;
 
     const float* srow0 = matM;
-    for (int x = 0; x < width * 5; x++) vsum[x] = srow0[x] * (m + 2);
+    for (int x = 0; x < width * 5; x++) vsum[x] = RND(srow0[x] * (m + 2));
     for (int y = 1; y < m; y++) {
         srow0 = matM + (size_t)(y < height - 1 ? y : height - 1) * width * 5;
-        for (int x = 0; x < width * 5; x++) vsum[x] += srow0[x];
+        for (int x = 0; x < width * 5; x++) vsum[x] = RND(vsum[x] + srow0[x]);
     }
     for (int y = 0; y < height; y++) {
         double g11, g12, g22, h1, h2;
         float* flow = flow_ + (size_t)y * width * 2;
         srow0 = matM + (size_t)(y - m - 1 > 0 ? y - m - 1 : 0) * width * 5;
         const float* srow1 = matM + (size_t)(y + m < height - 1 ? y + m : height - 1) * width * 5;
-        for (int x = 0; x < width * 5; x++) vsum[x] += srow1[x] - srow0[x];
+        for (int x = 0; x < width * 5; x++) vsum[x] = RND(vsum[x] + RND(srow1[x] - srow0[x]));
         for (int x = 0; x < (m + 1) * 5; x++) {
             vsum[-1 - x] = vsum[4 - x];
             vsum[width * 5 + x] = vsum[width * 5 + x - 5];
         }
-        g11 = vsum[0] * (m + 2); g12 = vsum[1] * (m + 2); g22 = vsum[2] * (m + 2);
-        h1 = vsum[3] * (m + 2); h2 = vsum[4] * (m + 2);
+        g11 = RND(vsum[0] * (m + 2)); g12 = RND(vsum[1] * (m + 2)); g22 = RND(vsum[2] * (m + 2));
+        h1 = RND(vsum[3] * (m + 2)); h2 = RND(vsum[4] * (m + 2));
         for (int x = 1; x < m; x++) {
-            g11 += vsum[x * 5]; g12 += vsum[x * 5 + 1]; g22 += vsum[x * 5 + 2];
-            h1 += vsum[x * 5 + 3]; h2 += vsum[x * 5 + 4];
+            g11 = RND(g11 + vsum[x * 5]); g12 = RND(g12 + vsum[x * 5 + 1]); g22 = RND(g22 + vsum[x * 5 + 2]);
+            h1 = RND(h1 + vsum[x * 5 + 3]); h2 = RND(h2 + vsum[x * 5 + 4]);
         }
         for (int x = 0; x < width; x++) {
-            g11 += vsum[(x + m) * 5] - vsum[(x - m) * 5 - 5];
-            g12 += vsum[(x + m) * 5 + 1] - vsum[(x - m) * 5 - 4];
-            g22 += vsum[(x + m) * 5 + 2] - vsum[(x - m) * 5 - 3];
-            h1 += vsum[(x + m) * 5 + 3] - vsum[(x - m) * 5 - 2];
-            h2 += vsum[(x + m) * 5 + 4] - vsum[(x - m) * 5 - 1];
-            double g11_ = g11 * scale, g12_ = g12 * scale, g22_ = g22 * scale, h1_ = h1 * scale, h2_ = h2 * scale;
-            double idet = 1. / (g11_ * g22_ - g12_ * g12_ + 1e-3);
-            flow[x * 2] = (float)((g11_ * h2_ - g12_ * h1_) * idet);
-            flow[x * 2 + 1] = (float)((g22_ * h1_ - g12_ * h2_) * idet);
+            g11 = RND(g11 + RND(vsum[(x + m) * 5] - vsum[(x - m) * 5 - 5]));
+            g12 = RND(g12 + RND(vsum[(x + m) * 5 + 1] - vsum[(x - m) * 5 - 4]));
+            g22 = RND(g22 + RND(vsum[(x + m) * 5 + 2] - vsum[(x - m) * 5 - 3]));
+            h1 = RND(h1 + RND(vsum[(x + m) * 5 + 3] - vsum[(x - m) * 5 - 2]));
+            h2 = RND(h2 + RND(vsum[(x + m) * 5 + 4] - vsum[(x - m) * 5 - 1]));
+            double g11_ = RND(g11 * scale), g12_ = RND(g12 * scale), g22_ = RND(g22 * scale), h1_ = RND(h1 * scale), h2_ = RND(h2 * scale);
+            double idet = RND(1. / RND(RND(RND(g11_ * g22_) - RND(g12_ * g12_)) + 1e-3));
+            if (sys) {
+                double* o = sys + ((size_t)y * width + x) * 7;
+                o[0] = g11_; o[1] = g12_; o[2] = g22_; o[3] = h1_; o[4] = h2_;
+                o[5] = flow[x * 2]; o[6] = flow[x * 2 + 1];
+            }
+            flow[x * 2] = (float)(RND(RND(g11_ * h2_) - RND(g12_ * h1_)) * idet);
+            flow[x * 2 + 1] = (float)(RND(RND(g22_ * h1_) - RND(g12_ * h2_)) * idet);
         }
         y1 = y == height - 1 ? height : y - block_size;
         if (update_matrices && (y1 == height || y1 >= y0 + min_update_stripe)) {
@@ -402,6 +414,19 @@ void fbo_blur_iter(const float* R0, const float* R1, float* flow_, float* matM, 
         }
     }
     free(_vsum);
+}
+#undef RND
+
+void fbo_blur_iter_sys(const float* R0, const float* R1, float* flow_, float* matM, int width, int height,
+                       int block_size, int update_matrices, double* sys)
+{
+    fbo_blur_iter_ex(R0, R1, flow_, matM, width, height, block_size, update_matrices, sys, 0);
+}
+
+void fbo_blur_iter(const float* R0, const float* R1, float* flow_, float* matM, int width, int height,
+                   int block_size, int update_matrices)
+{
+    fbo_blur_iter_sys(R0, R1, flow_, matM, width, height, block_size, update_matrices, 0);
 }
 
 /* resize(prevFlow -> (w,h), INTER_LINEAR) * (1/pyr_scale) */
@@ -434,8 +459,10 @@ void fbo_resize_flow(const float* prev, int pw, int ph, int w, int h, double mul
     }
 }
 
-/* FarnebackOpticalFlowImpl::calc, flags == 0 path. Returns 0 on success, <0 on bad arguments. */
-int fbo_calc(const uint8_t* prev, const uint8_t* next, int W, int H, const fbo_params* p, float* flow0)
+/* FarnebackOpticalFlowImpl::calc, flags == 0 path. Returns 0 on success, <0 on bad arguments.
+ * sys_last (nullable, H x W x 7 doubles): the finest layer's last sweep as fbo_blur_iter_sys reports it. */
+static int calc_ex(const uint8_t* prev, const uint8_t* next, int W, int H, const fbo_params* p, float* flow0, double* sys_last,
+                   int acc_float)
 {
     if (!prev || !next || !flow0 || W <= 0 || H <= 0) return -1;
     if (!(p->pyr_scale > 0 && p->pyr_scale < 1) || p->levels < 0 || p->winsize < 2 || p->iterations < 0 ||
@@ -463,11 +490,28 @@ int fbo_calc(const uint8_t* prev, const uint8_t* next, int W, int H, const fbo_p
         float* M = (float*)malloc(sizeof(float) * (size_t)w * h * 5);
         fbo_update_matrices(R[0], R[1], flow, w, h, M);
         for (int i = 0; i < p->iterations; i++)
-            fbo_blur_iter(R[0], R[1], flow, M, w, h, p->winsize, i < p->iterations - 1);
+            fbo_blur_iter_ex(R[0], R[1], flow, M, w, h, p->winsize, i < p->iterations - 1,
+                             (k == 0 && i == p->iterations - 1) ? sys_last : 0, acc_float);
         free(M); free(R[0]); free(R[1]);
         if (prevFlow) free(prevFlow);
         prevFlow = (k > 0) ? flow : 0;
         pw = w; ph = h;
     }
     return 0;
+}
+
+int fbo_calc_sys(const uint8_t* prev, const uint8_t* next, int W, int H, const fbo_params* p, float* flow0, double* sys_last)
+{
+    return calc_ex(prev, next, W, H, p, flow0, sys_last, 0);
+}
+
+int fbo_calc(const uint8_t* prev, const uint8_t* next, int W, int H, const fbo_params* p, float* flow0)
+{
+    return calc_ex(prev, next, W, H, p, flow0, 0, 0);
+}
+
+/* NOT OpenCV: calc() with float32 window sums (see fbo_blur_iter_ex); the sensitivity twin of oracle/tolerances.py. */
+int fbo_calc_f32sums(const uint8_t* prev, const uint8_t* next, int W, int H, const fbo_params* p, float* flow0)
+{
+    return calc_ex(prev, next, W, H, p, flow0, 0, 1);
 }

@@ -72,15 +72,18 @@ class Oracle:
         self.lib.fbo_update_matrices(_p(R0, C.c_float), _p(R1, C.c_float), _p(flow, C.c_float), w, h, _p(M, C.c_float))
         return M
 
-    def blur_iter(self, R0, R1, flow, M, winsize=12, update=True):
-        """One FarnebackUpdateFlow_Blur sweep; returns (new flow, new M) without touching the inputs."""
+    def blur_iter(self, R0, R1, flow, M, winsize=12, update=True, want_sys=False):
+        """One FarnebackUpdateFlow_Blur sweep; returns (new flow, new M) without touching the inputs -- and, with want_sys, the
+        (h, w, 7) float64 record (g11, g12, g22, h1, h2, u_before, v_before): the system every pixel was solved from and the flow
+        the sweep replaced."""
         h, w = flow.shape[:2]
         R0 = np.ascontiguousarray(R0, np.float32); R1 = np.ascontiguousarray(R1, np.float32)
         flow = np.array(flow, np.float32, order="C", copy=True)
         M = np.array(M, np.float32, order="C", copy=True)
-        self.lib.fbo_blur_iter(_p(R0, C.c_float), _p(R1, C.c_float), _p(flow, C.c_float), _p(M, C.c_float), w, h,
-                               winsize, int(bool(update)))
-        return flow, M
+        sys = np.empty((h, w, 7), np.float64) if want_sys else None
+        self.lib.fbo_blur_iter_sys(_p(R0, C.c_float), _p(R1, C.c_float), _p(flow, C.c_float), _p(M, C.c_float), w, h,
+                                   winsize, int(bool(update)), _p(sys, C.c_double) if want_sys else None)
+        return (flow, M, sys) if want_sys else (flow, M)
 
     def resize_flow(self, prev, w, h, mul):
         prev = np.ascontiguousarray(prev, np.float32)
@@ -89,17 +92,52 @@ class Oracle:
         self.lib.fbo_resize_flow(_p(prev, C.c_float), pw, ph, w, h, C.c_double(mul), _p(out, C.c_float))
         return out
 
-    def calc(self, prev, nxt, p=None):
-        """cv2.calcOpticalFlowFarneback(prev, next, None, *p) restated; returns float32 (H, W, 2)."""
+    def calc(self, prev, nxt, p=None, want_sys=False):
+        """cv2.calcOpticalFlowFarneback(prev, next, None, *p) restated; returns float32 (H, W, 2) -- and, with want_sys, the
+        (H, W, 7) float64 record of the finest layer's last sweep (see blur_iter; NaN when iterations == 0), from which
+        oracle/tolerances.py reads where the iteration has settled."""
         p = p or default_params()
         prev = np.ascontiguousarray(prev, np.uint8); nxt = np.ascontiguousarray(nxt, np.uint8)
         if prev.shape != nxt.shape or prev.ndim != 2:
             raise ValueError("prev/next must be equal-size single-channel u8 images")
         H, W = prev.shape
         flow = np.empty((H, W, 2), np.float32)
-        rc = self.lib.fbo_calc(_p(prev, C.c_uint8), _p(nxt, C.c_uint8), W, H, C.byref(p), _p(flow, C.c_float))
+        sys = np.full((H, W, 7), np.nan) if want_sys else None
+        rc = self.lib.fbo_calc_sys(_p(prev, C.c_uint8), _p(nxt, C.c_uint8), W, H, C.byref(p), _p(flow, C.c_float),
+                                   _p(sys, C.c_double) if want_sys else None)
         if rc != 0:
             raise ValueError(f"fbo_calc failed: {rc}")
+        return (flow, sys) if want_sys else flow
+
+    def calc_f32sums(self, prev, nxt, p=None):
+        """NOT OpenCV and never an expected value: calc() with every window sum and the 2x2 solve rounded to float32 (OpenCV sums
+        in double).  |calc - calc_f32sums| is how far the restatement's own result moves under float32 rounding of its sums."""
+        p = p or default_params()
+        prev = np.ascontiguousarray(prev, np.uint8); nxt = np.ascontiguousarray(nxt, np.uint8)
+        H, W = prev.shape
+        flow = np.empty((H, W, 2), np.float32)
+        rc = self.lib.fbo_calc_f32sums(_p(prev, C.c_uint8), _p(nxt, C.c_uint8), W, H, C.byref(p), _p(flow, C.c_float))
+        if rc != 0:
+            raise ValueError(f"fbo_calc_f32sums failed: {rc}")
+        return flow
+
+    def pyramid(self, prev, nxt, p=None, on_sweep=None):
+        """calc() driven layer by layer from Python with the stage functions above (bit-identical to calc(): tested).
+        on_sweep(k, it, flow, M_before, sys, R0, R1) is called after every sweep (tools/worst_pixel.py)."""
+        p = p or default_params()
+        prev = np.ascontiguousarray(prev, np.uint8); nxt = np.ascontiguousarray(nxt, np.uint8)
+        H, W = prev.shape
+        flow = None
+        for k in range(self.num_layers(W, H, p) - 1, -1, -1):
+            w, h, sigma, ksize = self.layer_dims(W, H, p, k)
+            flow = np.zeros((h, w, 2), np.float32) if flow is None else self.resize_flow(flow, w, h, 1.0 / p.pyr_scale)
+            R0, R1 = (self.polyexp(self.blur_resize(img, w, h, ksize, sigma), p.poly_n, p.poly_sigma) for img in (prev, nxt))
+            M = self.update_matrices(R0, R1, flow)
+            for it in range(p.iterations):
+                M_before = M
+                flow, M, sys = self.blur_iter(R0, R1, flow, M, p.winsize, it < p.iterations - 1, want_sys=True)
+                if on_sweep is not None:
+                    on_sweep(k, it, flow, M_before, sys, R0, R1)
         return flow
 
 

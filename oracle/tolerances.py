@@ -1,22 +1,48 @@
 """The ONE statement of the end-to-end flow tolerance (test infrastructure, like everything under oracle/).
 
 north_star: "flow fields match cv2.calcOpticalFlowFarneback on identical inputs to a stated EPE tolerance"; SURVEY 8(d) proposed
-mean <= 1e-2 px / p99.9 <= 1e-1 px "tighten after first measurement".  Measured over rounds 1 - 4 against the C restatement
+mean <= 1e-2 px / p99.9 <= 1e-1 px "tighten after first measurement".  Measured over rounds 1 - 6 against the C restatement
 (f32 device sums vs the f32 / f64 mix of OpenCV's CPU path, ten feedback iterations per layer): 1080p mean 2.5e-6 / p99.9 1.4e-4 /
 max 3.6e-3; worst of six unfriendly pictures mean 1.4e-5 / p99.9 1.3e-3 / max 2.2e-2; 4K with five layers mean 1.6e-5 / p99.9 1.9e-3 /
-max 6.5e-2.  Round 5's extended shape fuzz (tools/fuzz_shapes.py, 140 cases over two seeds) found the worst single pixel: 0.269 px on
-a 1048x925 frame with a four-layer pyramid (seed 123, case 10: mean 4.0e-5, p99.9 3.8e-3) -- an isolated pixel whose 2x2 system is
-nearly singular, where float32 and float64 sums part; the 0.15 px first set for the maximum was too tight for that and is 0.5 now.
-The mean and p99.9 gates sit a factor 2 - 7 above the worst measurement, so a dropped sweep, a wrong border weight or a
-half-precision intermediate (each moves the mean by >= 1e-3 px) fails every end-to-end test.
+max 6.5e-2.
+
+The gate (every pixel of a frame, GPU flow against fb_oracle.calc):
+
+    mean EPE <= 1e-4 px,  p99.9 <= 1e-2 px,  max <= 0.15 px.
+
+The ONE exception, and what it is (round 6; profiles/r06/worst_pixel.txt, profiles/r06/flow_gate_survey.txt).  The shape fuzz's worst
+frame (tools/fuzz_shapes.py seed 123 case 10 pair 5: 1048 x 925, five layers) holds a CLUSTER of 61 pixels above 0.15 px, worst 0.269.
+Round 5 called that "an isolated pixel whose 2x2 system is nearly singular" and set the maximum to 0.5 px for every pixel of every
+frame.  The probe shows otherwise: at that pixel det = 16.7 and the determinant loses 1.8x to cancellation -- well conditioned -- and
+ONE GPU sweep on the oracle's own M differs from the oracle's by 2e-6 px.  What the region is: a place where Farneback's fixed-point
+iteration does not settle (a false match 10 px off the true motion; the oracle's OWN flow still moves 3.3 px in the finest layer's
+last sweep), so the sweep-to-sweep map expands there and a 1e-6 px rounding difference grows by 2 - 5x per sweep across twenty
+sweeps of two layers (1.5e-4 -> 4.7e-3 px on layer 1, 5e-3 -> 0.27 on layer 0).  The restatement itself is that sensitive: with its
+window sums rounded to float32 (fb_oracle.calc_f32sums -- OpenCV sums in double) its own result moves by 1.13 px at that pixel.
+Over 80 M pixels of timed configurations, unfriendly pictures and 160 fuzz cases the GPU's error and that sensitivity S go together
+(worst frames: 0.269 / 1.13, 0.0879 / 0.0879, 0.0759 / 0.0758, 0.0486 / 0.0254 px) and no pixel with S < 0.1 px is off by more than
+0.062 px.  Hence:
+
+    a pixel is UNSTABLE when S = |calc - calc_f32sums|, taken as the maximum over the pixel's winsize window, is >= 0.15 px:
+    there the restatement cannot say what a float32 implementation (OpenCV's own SIMD / IPP builds included) returns
+    to better than the gate.  Unstable pixels may number at most 0.5 % of a frame and must still be within 0.5 px;
+    every other pixel is held to 0.15 px.
+
+A caller that does not hand over the twin (fb_oracle.calc_f32sums of the same frames) gets the strict gate everywhere: that is every
+end-to-end test, bench.py and smoke().  The mean and p99.9 gates sit a factor 2 - 7 above the worst measurement, so a dropped sweep,
+a wrong border weight or a half-precision intermediate (each moves the mean by >= 1e-3 px) fails every end-to-end test; a border or
+tile-seam defect of a single pixel fails the 0.15 px maximum unless the oracle itself is unstable there.
 
 Used by tests/, __graft_entry__.smoke() and bench.py's verification legs; nothing else states a flow gate.
 """
 import numpy as np
 
-FLOW_EPE_MEAN = 1e-4      # px, mean end-point error over a frame
-FLOW_EPE_P999 = 1e-2      # px, 99.9th percentile
-FLOW_EPE_MAX = 0.5        # px, any single pixel (worst measured: 0.269)
+FLOW_EPE_MEAN = 1e-4           # px, mean end-point error over a frame
+FLOW_EPE_P999 = 1e-2           # px, 99.9th percentile
+FLOW_EPE_MAX = 0.15            # px, any pixel the oracle is stable at (worst measured: 0.062, 4K / 5 layers)
+FLOW_UNSTABLE_S = 0.15         # px: the oracle's own float32-sums twin moves at least this far (window maximum) -> unstable pixel
+FLOW_EPE_MAX_UNSTABLE = 0.5    # px, any unstable pixel (worst measured: 0.269 where S = 1.13)
+FLOW_UNSTABLE_FRAC = 5e-3      # unstable pixels per frame at most (worst measured: 3.2e-3, 20-px constant blocks -- a frame inside the strict gate; 1.9e-3 on the fuzz's worst frame)
 FLOW_GATE_TEXT = f"mean <= {FLOW_EPE_MEAN:g} px, p99.9 <= {FLOW_EPE_P999:g} px, max <= {FLOW_EPE_MAX:g} px"
 
 
@@ -25,18 +51,83 @@ def epe(a, b) -> np.ndarray:
     return np.hypot(d[..., 0], d[..., 1])
 
 
-def flow_epe_ok(e) -> bool:
-    """True when an end-point-error field is inside the gate (NaN anywhere fails)."""
+def _window_max(a, radius):
+    """maximum over the (2 radius + 1)^2 neighbourhood, edges replicated"""
+    for axis in (0, 1):
+        n = a.shape[axis]
+        p = np.take(a, np.clip(np.arange(-radius, n + radius), 0, n - 1), axis=axis)
+        out = a.copy()
+        for d in range(2 * radius + 1):
+            np.maximum(out, np.take(p, np.arange(d, d + n), axis=axis), out=out)
+        a = out
+    return a
+
+
+def sensitivity(exp, twin, radius=6) -> np.ndarray:
+    """S of the module docstring: |exp - twin| (fb_oracle.calc vs fb_oracle.calc_f32sums), maximum over the (2 radius + 1)^2
+    window a pixel's 2x2 system is summed over (radius = winsize // 2)."""
+    return _window_max(epe(twin, exp), radius)
+
+
+def unstable_mask(exp, twin, radius=6) -> np.ndarray:
+    return sensitivity(exp, twin, radius) >= FLOW_UNSTABLE_S
+
+
+def last_step(exp, record, radius=6):
+    """How far the ORACLE's own flow still moved in the finest layer's last sweep (px), per pixel, as the maximum over the
+    (2 radius + 1)^2 window.  `record` = fb_oracle.calc(want_sys=True)[1].  Diagnostic (tools/worst_pixel.py), not a gate."""
+    r = np.asarray(record, np.float64)
+    d = np.hypot(np.asarray(exp, np.float64)[..., 0] - r[..., 5], np.asarray(exp, np.float64)[..., 1] - r[..., 6])
+    return _window_max(np.where(np.isnan(d), 0.0, d), radius)
+
+
+def conditioning(sys):
+    """(det, cancel) of the oracle's 2x2 systems (..., >= 5) = (g11, g12, g22, h1, h2, ...) (fb_oracle.calc(want_sys=True)):
+    det = g11 g22 - g12^2 and cancel = (g11 g22 + g12^2) / (|det| + 1e-3), the factor by which a relative rounding error of the
+    window sums grows in the solve's denominator det + 1e-3.  Diagnostic (tools/worst_pixel.py), not a gate: the worst pixels
+    measured are well conditioned."""
+    s = np.asarray(sys, np.float64)
+    a, b = s[..., 0] * s[..., 2], s[..., 1] * s[..., 1]
+    det = a - b
+    cancel = (a + b) / (np.abs(det) + 1e-3)
+    return np.where(np.isnan(det), np.inf, det), np.where(np.isnan(cancel), 1.0, cancel)
+
+
+def flow_gate(e, unstable=None):
+    """None when the end-point-error field `e` (H, W) is inside the gate, else the name of the first gate it fails.
+    `unstable`: boolean (H, W) from unstable_mask(), or None = no pixel is excused."""
     e = np.asarray(e)
-    return bool(np.isfinite(e).all() and e.mean() <= FLOW_EPE_MEAN and np.percentile(e, 99.9) <= FLOW_EPE_P999 and e.max() <= FLOW_EPE_MAX)
+    if not np.isfinite(e).all():
+        return "non-finite EPE"
+    if e.mean() > FLOW_EPE_MEAN:
+        return "mean EPE"
+    if np.percentile(e, 99.9) > FLOW_EPE_P999:
+        return "p99.9 EPE"
+    if unstable is None or not unstable.any():
+        return None if e.max() <= FLOW_EPE_MAX else "max EPE"
+    if unstable.mean() > FLOW_UNSTABLE_FRAC:
+        return "unstable pixel count"
+    if e[unstable].max() > FLOW_EPE_MAX_UNSTABLE:
+        return "max EPE (unstable pixels)"
+    if (~unstable).any() and e[~unstable].max() > FLOW_EPE_MAX:
+        return "max EPE (stable pixels)"
+    return None
 
 
-def check_flow(got, exp, tag="") -> np.ndarray:
-    """assert `got` (..., 2) matches `exp` inside the gate; returns the EPE field."""
+def flow_epe_ok(e, unstable=None) -> bool:
+    """True when an end-point-error field is inside the gate (NaN anywhere fails)."""
+    return flow_gate(e, unstable) is None
+
+
+def check_flow(got, exp, tag="", twin=None, radius=6) -> np.ndarray:
+    """assert `got` (H, W, 2) matches `exp` inside the gate; returns the EPE field.  `twin` = fb_oracle.calc_f32sums of the same
+    frames switches the unstable-pixel class on (radius = winsize // 2); without it every pixel is held to FLOW_EPE_MAX."""
     assert np.isfinite(np.asarray(got)).all(), (tag, "non-finite flow")
     e = epe(got, exp)
+    unstable = None if twin is None else unstable_mask(exp, twin, radius)
+    failed = flow_gate(e, unstable)
     stats = (tag, float(e.mean()), float(np.percentile(e, 99.9)), float(e.max()))
-    assert e.mean() <= FLOW_EPE_MEAN, ("mean EPE",) + stats
-    assert np.percentile(e, 99.9) <= FLOW_EPE_P999, ("p99.9 EPE",) + stats
-    assert e.max() <= FLOW_EPE_MAX, ("max EPE",) + stats
+    if unstable is not None:
+        stats += (f"{int(unstable.sum())} unstable pixels", float(e[~unstable].max()) if (~unstable).any() else 0.0)
+    assert failed is None, (failed,) + stats
     return e

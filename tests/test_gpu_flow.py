@@ -3,7 +3,8 @@
 
 Tolerances (floating point; the CPU path mixes f32 storage with f64 accumulators, the GPU path is f32 throughout):
   stages    absolute, stated per test
-  flow      end-point error vs the oracle: mean <= 1e-4 px, p99.9 <= 1e-2 px, max <= 0.5 px: oracle/tolerances.py   (tightened to the measured level; north_star "stated EPE tolerance")
+  flow      end-point error vs the oracle: mean <= 1e-4 px, p99.9 <= 1e-2 px, max <= 0.15 px (0.5 px only where the oracle itself is unstable and says so):
+            oracle/tolerances.py   (tightened to the measured level; north_star "stated EPE tolerance")
 PARITY UNPINNED vs cv2 itself: OpenCV is not installable here (see oracle/farneback_oracle.c)."""
 import os
 
@@ -220,10 +221,44 @@ def test_shape_and_parameter_fuzz(mav):
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_shapes.py"), "15", "7"], cwd=root, capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0 and "all 15 cases passed" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
-    # a second seed whose case 10 (1048 x 925, four layers, 3 pairs) holds the worst single-pixel EPE any fuzz run has shown: 0.269 px
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_shapes.py"), "11", "123"], cwd=root, capture_output=True,
-                         text=True, timeout=600)
-    assert out.returncode == 0 and "all 11 cases passed" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_fuzz_worst_frame_is_unstable_in_the_oracle_itself(mav, fb_oracle):
+    """tools/fuzz_shapes.py seed 123 case 10 (1048 x 925, five layers, six pairs): pair 5 holds the worst end-point error any run has
+    shown, a cluster of pixels up to 0.269 px off.  Pinned here as what profiles/r06/worst_pixel.txt shows it to be: NOT an
+    ill-conditioned 2x2 system (the determinant at the worst pixel loses < 5x to cancellation) but a region where Farneback's
+    iteration does not settle, so that the restatement's own float32-sums twin moves by more than a pixel there.  Every pixel
+    outside such regions is within 0.15 px, the regions are < 0.5 % of the frame and within 0.5 px (oracle/tolerances.py)."""
+    import sys, os
+    from mavflow import _lib
+    from oracle import tolerances as tol
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    try:
+        from tools.fuzz_shapes import fuzz_cases
+    finally:
+        sys.path.remove(root)
+    cs = list(fuzz_cases(11, 123))[10]
+    assert (cs["W"], cs["H"], cs["B"], cs["fb"].levels) == (1048, 925, 6, 5)
+    with _lib.Context(cs["W"], cs["H"], cs["B"], cs["fb"]) as c:
+        got = c.farneback(cs["prev"], cs["nxt"])
+    n_strict_failures = 0
+    for b in range(cs["B"]):
+        ref, rec = fb_oracle.calc(cs["prev"][b], cs["nxt"][b], cs["po"], want_sys=True)
+        twin = fb_oracle.calc_f32sums(cs["prev"][b], cs["nxt"][b], cs["po"])
+        e = tol.check_flow(got[b], ref, f"pair {b}", twin)                     # the gate, unstable class on
+        un = tol.unstable_mask(ref, twin)
+        if not tol.flow_epe_ok(e):                                             # the strict gate fails ...
+            n_strict_failures += 1
+            bad = e > tol.FLOW_EPE_MAX
+            assert bad.any() and un[bad].all(), "... only on pixels the oracle is unstable at"
+            y, x = np.unravel_index(int(e.argmax()), e.shape)
+            assert tol.conditioning(rec[y, x][None])[1][0] < 5.0, "and the worst of them is a WELL conditioned system"
+            assert tol.sensitivity(ref, twin)[y, x] > e[y, x], "where the oracle's own twin moves further than the GPU's flow"
+            assert tol.last_step(ref, rec)[y, x] > 1.0, "because its iteration still moves by pixels per sweep"
+            print(f"\npair {b}: max EPE {e.max():.3f} px at ({x}, {y}); {int(un.sum())} unstable pixels ({un.mean():.2e} of the frame); "
+                  f"max EPE outside them {e[~un].max():.3e} px")
+    assert n_strict_failures <= 1
 
 
 def test_overlapped_upload_path(mav):

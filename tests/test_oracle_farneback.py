@@ -120,3 +120,69 @@ def test_oracle_vs_cv2_when_available(fb_oracle):
     got = fb_oracle.calc(f0, f1)
     e = np.hypot(got[..., 0] - ref[..., 0], got[..., 1] - ref[..., 1])
     assert e.mean() <= 1e-3 and e.max() <= 1e-1, (e.mean(), e.max())
+
+
+# ---- the checker's view of its own stability (oracle/tolerances.py, round 6) ---------------------------------------------------------
+def test_sweep_record_and_python_driven_pyramid(fb_oracle):
+    """calc(want_sys) changes nothing about the flow; the record holds the system the flow was solved from and the flow the sweep
+    replaced; the pyramid driven layer by layer from Python (tools/worst_pixel.py) is calc() bit for bit."""
+    f0, f1, _ = synth.make_pair(200, 150, 5, k=0.02, patch=False)
+    p = fb_oracle_params(levels=2)
+    flow = fb_oracle.calc(f0, f1, p)
+    flow2, rec = fb_oracle.calc(f0, f1, p, want_sys=True)
+    assert np.array_equal(flow, flow2) and rec.shape == (150, 200, 7) and np.isfinite(rec).all()
+    g11, g12, g22, h1, h2 = (rec[..., i] for i in range(5))
+    idet = 1.0 / (g11 * g22 - g12 * g12 + 1e-3)
+    assert np.array_equal(((g11 * h2 - g12 * h1) * idet).astype(np.float32), flow[..., 0])
+    assert np.array_equal(((g22 * h1 - g12 * h2) * idet).astype(np.float32), flow[..., 1])
+    seen = []
+    staged = fb_oracle.pyramid(f0, f1, p, lambda k, it, fl, M, s, R0, R1: seen.append((k, it, fl.copy(), s)))
+    assert np.array_equal(staged, flow)
+    assert fb_oracle.num_layers(200, 150, p) == 2                          # 0.16 * 150 < 32: the third layer is not built
+    assert [(k, it) for k, it, _, _ in seen] == [(k, it) for k in (1, 0) for it in range(10)]
+    assert np.array_equal(seen[-1][3], rec)                               # the record IS the finest layer's last sweep
+    assert np.array_equal(seen[-2][2], rec[..., 5:7].astype(np.float32))   # "before" = the sweep before it
+
+
+def test_f32sums_twin_is_close_where_the_iteration_settles(fb_oracle):
+    """The sensitivity twin (float32 window sums; NOT OpenCV) stays within the flow gate of calc() on a friendly texture: the gate's
+    unstable class is empty there."""
+    from oracle import tolerances as tol
+    f0, f1, _ = synth.make_pair(320, 240, 3)
+    ref, twin = fb_oracle.calc(f0, f1), fb_oracle.calc_f32sums(f0, f1)
+    assert not np.array_equal(ref, twin)
+    tol.check_flow(twin, ref, "twin")
+    assert not tol.unstable_mask(ref, twin).any()
+
+
+def test_flow_gate_classes():
+    """oracle/tolerances.py: 0.15 px everywhere; up to 0.5 px only on pixels the oracle itself is unstable at, whose count is bounded."""
+    from oracle import tolerances as tol
+    H, W = 200, 300
+    exp = np.zeros((H, W, 2), np.float32)
+    got = exp.copy()
+    got[100, 150, 0] = 0.2                                             # one pixel off by 0.2 px
+    with pytest.raises(AssertionError, match="max EPE"):
+        tol.check_flow(got, exp)                                       # strict: no twin, no excuse
+    twin = exp.copy()
+    with pytest.raises(AssertionError, match="stable pixels"):
+        tol.check_flow(got, exp, "", twin)                             # the oracle is stable there: still a failure
+    twin[98, 152, 1] = 0.3                                             # the oracle's own twin moves 0.3 px inside the pixel's window
+    e = tol.check_flow(got, exp, "", twin)
+    assert e.max() == pytest.approx(0.2) and tol.unstable_mask(exp, twin).sum() == 13 * 13
+    got[100, 150, 0] = 0.6
+    with pytest.raises(AssertionError, match="unstable pixels"):
+        tol.check_flow(got, exp, "", twin)                             # even an unstable pixel stays within 0.5 px
+    got[100, 150, 0] = 0.2
+    got[10, 10, 1] = 0.2                                               # a second pixel, outside the unstable window
+    with pytest.raises(AssertionError, match="stable pixels"):
+        tol.check_flow(got, exp, "", twin)
+    got[10, 10, 1] = 0.0
+    twin[::12, ::12, 0] = 0.3                                          # the oracle unstable (nearly) everywhere: not a frame to excuse
+    with pytest.raises(AssertionError, match="unstable pixel count"):
+        tol.check_flow(got, exp, "", twin)
+    got[5, 5, 0] = np.nan
+    with pytest.raises(AssertionError, match="non-finite"):
+        tol.check_flow(got, exp, "", exp.copy())
+    assert not tol.flow_epe_ok(np.full((4, 4), np.nan)) and tol.flow_epe_ok(np.zeros((4, 4)))
+    assert tol.FLOW_EPE_MAX == 0.15 and tol.FLOW_EPE_MAX_UNSTABLE == 0.5
