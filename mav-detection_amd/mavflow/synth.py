@@ -7,9 +7,27 @@ radial warp are separable in x and y, so whole frames are two small matrix produ
 """
 from __future__ import annotations
 
+import contextlib
+
 import numpy as np
 
 N_WAVES = 32
+
+
+@contextlib.contextmanager
+def _one_blas_thread():
+    """The two matrix products below run on ONE BLAS thread.  Why a frame synthesiser cares: OpenBLAS starts one thread per core it can
+    SEE (64 on the 256-core GPU hosts) and its idle threads spin for tens of milliseconds after a product before they sleep; inside a
+    container whose cgroup grants a CPU-time quota (16 cores per 100 ms period there) the spinners burn the quota and the kernel then
+    freezes EVERY thread of the cgroup until the period ends -- a one-pair GPU call issued 30 - 80 ms after a synthesis took 25 - 80 ms
+    instead of 0.3 (profiles/r06/stall_bisect.txt: throttle counters of the cgroup, gone with one BLAS thread).  No-op without threadpoolctl."""
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:
+        yield
+        return
+    with threadpool_limits(limits=1, user_api="blas"):
+        yield
 
 
 def _texture_params(rng: np.random.Generator):
@@ -32,12 +50,14 @@ def _eval_separable(xs: np.ndarray, ys: np.ndarray, fx, fy, amp, phase) -> np.nd
     by = 2 * np.pi * np.outer(fy, ys)                            # (J, H)
     left = np.concatenate([np.cos(by) * amp[:, None], np.sin(by) * amp[:, None]], axis=0).T   # (H, 2J)
     right = np.concatenate([np.sin(ax), np.cos(ax)], axis=0)                                  # (2J, W)
-    return left @ right
+    with _one_blas_thread():
+        return left @ right
 
 
 def _eval_points(px: np.ndarray, py: np.ndarray, fx, fy, amp, phase) -> np.ndarray:
     arg = 2 * np.pi * (fx[:, None, None] * px[None] + fy[:, None, None] * py[None]) + phase[:, None, None]
-    return np.tensordot(amp, np.sin(arg), axes=1)
+    with _one_blas_thread():
+        return np.tensordot(amp, np.sin(arg), axes=1)
 
 
 def true_flow(W: int, H: int, k: float = 0.01, patch=True) -> np.ndarray:
