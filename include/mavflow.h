@@ -262,10 +262,16 @@ int mav_upload_fence(mav_ctx*);
  * Pageable sources are copied into a ring of page-locked chunks by a few worker threads (option "upload_threads", default 4: the
  * calling thread plus three; settable until the first call) and every chunk crosses PCIe while the next one is being filled;
  * sources that are page-locked already (mav_host_alloc) are sent from where they are.  On return every source has been READ (the
- * caller may overwrite it); the transfers themselves complete on the copy stream -- mav_upload_fence orders the compute stream
- * behind them.  ordered != 0: as mav_upload_async, the copies wait for everything enqueued on the compute stream so far;
- * ordered == 0: as mav_upload_async_unordered.  The same pointer may appear more than once (replication). */
-int mav_upload_gather(mav_ctx*, void* dst_dev, const void* const* src_host, int count, size_t bytes_each, int ordered);
+ * caller may overwrite it) -- for a page-locked source that means the call waits for its transfer (copy stream), or, with option
+ * "inline_uploads" (where the transfer would queue behind the compute stream's kernels), stages it like a pageable one; the
+ * transfers of staged sources complete on the copy stream -- mav_upload_fence orders the compute stream behind them.
+ * flags: MAV_GATHER_ORDERED: as mav_upload_async, the copies wait for everything enqueued on the compute stream so far (without it:
+ * as mav_upload_async_unordered).  MAV_GATHER_SOURCES_HELD: the caller keeps every source alive and unchanged until work enqueued
+ * behind the copies has completed (a marker recorded after mav_upload_fence has fired): page-locked sources are then read by the DMA
+ * engine whenever the stream gets there and the call waits for nothing.  The same pointer may appear more than once (replication). */
+#define MAV_GATHER_ORDERED 1
+#define MAV_GATHER_SOURCES_HELD 2
+int mav_upload_gather(mav_ctx*, void* dst_dev, const void* const* src_host, int count, size_t bytes_each, int flags);
 /* Device -> host copy enqueued on the context's stream (dst_host should be page-locked: mav_host_alloc); complete after mav_sync or
  * after a marker recorded behind it. */
 int mav_download_async(mav_ctx*, void* dst_host, const void* src_dev, size_t bytes);
@@ -275,7 +281,88 @@ int mav_download_async(mav_ctx*, void* dst_host, const void* src_dev, size_t byt
 int mav_marker_create(mav_ctx*, void** marker_out);
 int mav_marker_record(mav_ctx*, void* marker);
 int mav_marker_wait(mav_ctx* /* may be NULL */, void* marker);
+/* *done = 1 when everything the marker was recorded behind has completed (or it was never recorded), else 0; never blocks. */
+int mav_marker_query(mav_ctx* /* may be NULL */, void* marker, int* done);
 int mav_marker_destroy(mav_ctx* /* may be NULL */, void* marker);
+
+/* ---- one iteration of the reference's loop as ONE call ---------------------------------------------------------------------------
+ * Processor.run_detection's body [src/processor.py:283-362] is, per frame: read a frame, get the flow (Farneback here), derotate,
+ * FoE, phi, masks, TPR / FPR counts against the segmentation, store a record.  Through the entry points above that is a dozen calls
+ * per frame (gather upload, fence, Farneback, markers, parameter upload, detect, counts, download, marker) -- at 1280x720, where the
+ * GPU needs 0.18 ms per frame, the calling thread needs longer than that to issue them.  mav_frame_step describes the whole
+ * iteration; mav_frame_step_dev enqueues it in one call, and mav_frame_step_post hands it to the context's WORKER thread (created by
+ * the first post) and returns at once, so that a single-threaded host loop feeding two or three contexts in turn ("lanes") pays a
+ * few microseconds per frame and the contexts enqueue side by side.  Every part is optional; what is present runs in this order:
+ *   1. the host waits for `wait_before` markers (the last readers of buffers the uploads overwrite),
+ *   2. uploads: the packed parameter block (par_host -> par_dev; par_host should be page-locked) and the `gather` lists (host arrays ->
+ *      device: frames, a host flow field, per-pair sky masks / ground truth), as mav_upload_gather does, then the upload fence,
+ *   3. BGR -> gray of `n_bgr` frames (mav_bgr2gray_dev),
+ *   4. compute_flow: flow_dev = Farneback(prev_dev, next_dev) for n pairs (mav_farneback_dev; the frame-sequence layout is
+ *      recognised), then the `record_after_flow` markers ("the frame buffers have been read"),
+ *   5. detection on flow_dev (mav_detect_dev): samples / omega / dt / frame0 at their offsets inside par_dev, sky_dev, masks,
+ *      n records to out_dev; with gt_dev the TPR / FPR counts of both masks (mav_tpr_fpr_counts_dev) to out_dev + off_counts_*,
+ *   6. out_dev[0 : out_bytes] -> out_host (page-locked), then `record_done`.
+ * The library copies the struct and the pointer arrays it refers to (gather[i].src_host, wait_before, record_after_flow) when the
+ * step is posted; the HOST BUFFERS themselves (frames, par_host, out_host) must stay valid and unchanged until the step's
+ * `record_done` marker has fired (mav_frame_step_wait). */
+typedef struct {
+    const void* const* src_host; /* count host arrays of bytes_each bytes ... */
+    int count;
+    size_t bytes_each;
+    void* dst_dev;               /* ... to dst_dev + i * bytes_each */
+} mav_gather;
+#define MAV_STEP_MAX_GATHER 4
+typedef struct mav_frame_step {
+    int n; /* pairs (1 <= n <= max_batch) */
+    /* 1. */
+    void* const* wait_before;
+    int n_wait_before;
+    /* 2. */
+    const void* par_host;
+    void* par_dev;
+    size_t par_bytes;
+    mav_gather gather[MAV_STEP_MAX_GATHER];
+    int n_gather;
+    /* 3. */
+    const uint8_t* bgr_dev; /* n_bgr frames (H, W, 3) u8, gathered there by a `gather` entry */
+    int n_bgr;
+    uint8_t* gray_dev;      /* n_bgr frames (H, W) u8 out */
+    /* 4. */
+    int compute_flow;
+    const uint8_t* prev_dev; /* n gray frames each */
+    const uint8_t* next_dev;
+    float* flow_dev;         /* (n, H, W, 2) float32: written by step 4 (NULL: into the context's own flow buffer), or gathered in step 2, or resident */
+    void* const* record_after_flow;
+    int n_record_after_flow;
+    /* 5. */
+    int detect;              /* 0: stop after step 4 (a flow-only step) */
+    size_t off_samples, off_omega, off_dt, off_frame0; /* byte offsets inside par_dev */
+    int has_omega, has_frame0;
+    const uint8_t* sky_dev;  /* n sky masks or NULL */
+    const uint8_t* gt_dev;   /* ground truth for the counts, or NULL: no counts */
+    int gt_images;           /* n, or 1 = one image shared by every pair */
+    mav_foe_params foe;
+    mav_thr_params thr;
+    uint8_t* mask_fixed_dev; /* (n, H, W) u8 each */
+    uint8_t* mask_dyn_dev;
+    void* out_dev;           /* n mav_result records at offset 0 */
+    size_t off_counts_fixed, off_counts_dyn; /* n x 4 int64 each, inside out_dev */
+    /* 6. */
+    void* out_host;
+    size_t out_bytes;
+    void* record_done;
+} mav_frame_step;
+int mav_frame_step_dev(mav_ctx*, const mav_frame_step*);
+/* Post the step to the context's worker thread.  From the first post on until mav_worker_drain (or mav_destroy) the worker is the
+ * thread that owns the context: the caller may post further steps and wait for tickets, and must call mav_worker_drain before any
+ * other entry point of this context (the Python binding does so by itself).  *ticket identifies the step. */
+int mav_frame_step_post(mav_ctx*, const mav_frame_step*, uint64_t* ticket);
+/* Block until step `ticket` has been enqueued by the worker and, when `marker` is not NULL (the step's record_done), until that
+ * marker has fired.  Returns the step's own return code (and sets mav_last_error to its message). */
+int mav_frame_step_wait(mav_ctx*, uint64_t ticket, void* marker);
+/* Block until the worker has enqueued every posted step (device work may still be running); returns the first failed step's code
+ * since the last drain, MAV_OK if none.  No-op for a context that never posted. */
+int mav_worker_drain(mav_ctx*);
 
 /* Frame decode in front of the path [src/datasets/dataset.py:57,223-230: cv2.VideoCapture over image_%05d.png; src/farneback.py:17-21]:
  * the un-filtering pass of a PNG image, host memory, no context.  raw = the inflated IDAT stream of a non-interlaced image (per row a

@@ -12,6 +12,8 @@
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <deque>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -283,7 +285,9 @@ struct mav_ctx {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;   // uploads that overlap the compute stream (mav_upload_async / mav_upload_fence)
     hipEvent_t copy_done = nullptr, compute_mark = nullptr;
+    hipEvent_t gather_done = nullptr;    // mav_upload_gather: "the page-locked sources sent from where they are have been read"
     struct Stager* stager = nullptr;     // mav_upload_gather: page-locked ring + worker threads (created by its first call)
+    struct Worker* worker = nullptr;     // mav_frame_step_post: the thread that enqueues posted steps (created by the first post)
     int upload_threads = 4;              // option "upload_threads"
     bool inline_uploads = false;         // option "inline_uploads": uploads go on the compute stream (no copy stream, no cross-stream events)
     const float* last_flow = nullptr;    // where the latest farneback / process_batch call wrote its flow (mav_last_flow_dev)
@@ -520,10 +524,12 @@ static int sync_all_streams(mav_ctx* c)
     return MAV_OK;
 }
 
+static void stop_worker(mav_ctx* c);
 extern "C" int mav_destroy(mav_ctx* c)
 {
     if (!c) return MAV_OK;
     hipSetDevice(c->device);
+    stop_worker(c);                  // (enqueues what was posted, then leaves)
     (void)sync_all_streams(c);
     if (c->copy_stream) hipStreamSynchronize(c->copy_stream);
     if (c->stager) { c->stager->shutdown(); delete c->stager; c->stager = nullptr; }
@@ -539,7 +545,7 @@ extern "C" int mav_destroy(mav_ctx* c)
     for (auto& blk : c->scratch) if (blk.p) hipFree(blk.p);
     for (auto& r : c->prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     if (c->prof_base) hipEventDestroy(c->prof_base);
-    for (hipEvent_t e : {c->t0, c->t1, c->copy_done, c->compute_mark, c->pif_fork, c->pif_join}) if (e) hipEventDestroy(e);
+    for (hipEvent_t e : {c->t0, c->t1, c->copy_done, c->compute_mark, c->gather_done, c->pif_fork, c->pif_join}) if (e) hipEventDestroy(e);
     for (hipStream_t st : {c->pair_stream, c->copy_stream, c->stream}) if (st) hipStreamDestroy(st);
     delete c;
     return MAV_OK;
@@ -865,6 +871,11 @@ extern "C" int mav_upload_fence(mav_ctx* c)
     return MAV_OK;
 }
 
+static int ensure_gather_event(mav_ctx* c)
+{
+    if (!c->gather_done) HIPCHK(hipEventCreateWithFlags(&c->gather_done, hipEventDisableTiming));
+    return MAV_OK;
+}
 static int ensure_stager(mav_ctx* c)
 {
     if (c->stager) return MAV_OK;
@@ -893,15 +904,20 @@ static int host_ptr_kind(const void* p)
     return a.type == hipMemoryTypeManaged ? 1 : 0;
 }
 
-extern "C" int mav_upload_gather(mav_ctx* c, void* dst_dev, const void* const* src_host, int count, size_t bytes_each, int ordered)
+extern "C" int mav_upload_gather(mav_ctx* c, void* dst_dev, const void* const* src_host, int count, size_t bytes_each, int flags)
 {
     if (!c || !dst_dev || !src_host || count < 1) return fail(MAV_ERR_ARG, "mav_upload_gather: NULL argument or count < 1");
     for (int i = 0; i < count; i++) if (!src_host[i]) return fail(MAV_ERR_ARG, "mav_upload_gather: source %d is NULL", i);
     if (!bytes_each) return MAV_OK;
+    const bool ordered = (flags & MAV_GATHER_ORDERED) != 0, held = (flags & MAV_GATHER_SOURCES_HELD) != 0;
     std::vector<int> kind(count);
     for (int i = 0; i < count; i++) {
         kind[i] = (i > 0 && src_host[i] == src_host[i - 1]) ? kind[i - 1] : host_ptr_kind(src_host[i]);
         if (kind[i] < 0) return fail(MAV_ERR_ARG, "mav_upload_gather: source %d is a device pointer (host arrays expected)", i);
+        // "on return every source has been read": a page-locked source is read by the DMA engine when the stream gets there.  With
+        // inline uploads that is behind whatever the compute stream still has to run -- waiting for it would drain the lane -- so such
+        // a source is staged like a pageable one unless the caller vouches that it holds its sources (MAV_GATHER_SOURCES_HELD)
+        if (kind[i] == 1 && !held && c->inline_uploads) kind[i] = 0;
     }
     HIPCHK(hipSetDevice(c->device));
     if (!c->inline_uploads) CHK(ensure_copy_stream(c));
@@ -914,6 +930,7 @@ extern "C" int mav_upload_gather(mav_ctx* c, void* dst_dev, const void* const* s
     Stager* s = nullptr;
     size_t fill = 0;                           // bytes staged in the chunk being filled
     size_t chunk_dst = 0;                      // device offset the chunk being filled starts at
+    bool direct = false;                       // a page-locked source was sent from where it is
     auto flush = [&]() -> int {                // copy the collected segments, send the chunk
         if (!fill) return MAV_OK;
         const unsigned k = s->next_chunk % Stager::NCHUNK;
@@ -938,6 +955,7 @@ extern "C" int mav_upload_gather(mav_ctx* c, void* dst_dev, const void* const* s
         if (kind[i] == 1) {                    // straight from where it is; whatever was staged before it goes first (keeps nothing waiting)
             if (s) CHK(flush());
             HIPCHK(hipMemcpyAsync(dst + dev_off, src, bytes_each, hipMemcpyHostToDevice, cs));
+            direct = true;
             continue;
         }
         if (!s) { CHK(ensure_stager(c)); s = c->stager; }
@@ -954,7 +972,14 @@ extern "C" int mav_upload_gather(mav_ctx* c, void* dst_dev, const void* const* s
     }
     if (s) {
         CHK(flush());
-        // the sources have been read; the ring's last transfers may still be in flight (the next call waits for a slot before it refills it)
+        // the staged sources have been read; the ring's last transfers may still be in flight (the next call waits for a slot before it refills it)
+    }
+    if (direct && !held) {
+        // page-locked sources sent from where they are (copy stream: nothing but copies ahead of them): the caller may overwrite them
+        // when this call returns, so wait until the engine has read them
+        CHK(ensure_gather_event(c));
+        HIPCHK(hipEventRecord(c->gather_done, cs));
+        HIPCHK(hipEventSynchronize(c->gather_done));
     }
     return MAV_OK;
 }
@@ -989,6 +1014,16 @@ extern "C" int mav_marker_wait(mav_ctx* c, void* marker)
     (void)c;                     // waiting needs no context: a marker may outlive the one it was recorded on (mav_destroy drains the streams)
     if (!marker) return fail(MAV_ERR_ARG, "mav_marker_wait: NULL marker");
     HIPCHK(hipEventSynchronize((hipEvent_t)marker));
+    return MAV_OK;
+}
+extern "C" int mav_marker_query(mav_ctx* c, void* marker, int* done)
+{
+    (void)c;
+    if (!marker || !done) return fail(MAV_ERR_ARG, "mav_marker_query: NULL argument");
+    const hipError_t e = hipEventQuery((hipEvent_t)marker);
+    if (e == hipSuccess) { *done = 1; return MAV_OK; }
+    if (e == hipErrorNotReady) { (void)hipGetLastError(); *done = 0; return MAV_OK; }
+    HIPCHK(e);
     return MAV_OK;
 }
 extern "C" int mav_marker_destroy(mav_ctx* c, void* marker)
@@ -1716,6 +1751,173 @@ extern "C" int mav_process_batch_dev(mav_ctx* c, const uint8_t* prev, const uint
     }
     CHK(mav_farneback_dev(c, prev, next, batch, flow));
     return mav_detect_dev(c, flow, samples, omega, dt, frame0, sky, batch, fp, tp, phi, mask_fixed, mask_dyn, results);
+}
+
+// ---- one iteration of the reference's loop as one call (include/mavflow.h: mav_frame_step) ---------------------------------------
+static int frame_step_enqueue(mav_ctx* c, const mav_frame_step* s)
+{
+    if (s->n < 1 || s->n > c->max_batch) return fail(MAV_ERR_ARG, "mav_frame_step: n %d outside [1, %d]", s->n, c->max_batch);
+    if (s->n_gather < 0 || s->n_gather > MAV_STEP_MAX_GATHER) return fail(MAV_ERR_ARG, "mav_frame_step: n_gather %d outside [0, %d]", s->n_gather, (int)MAV_STEP_MAX_GATHER);
+    if (s->n_wait_before < 0 || s->n_record_after_flow < 0 || (s->n_wait_before && !s->wait_before) || (s->n_record_after_flow && !s->record_after_flow))
+        return fail(MAV_ERR_ARG, "mav_frame_step: marker list without markers");
+    if (s->compute_flow && (!s->prev_dev || !s->next_dev)) return fail(MAV_ERR_ARG, "mav_frame_step: compute_flow needs prev_dev and next_dev");
+    if (s->detect && ((!s->flow_dev && !s->compute_flow) || !s->par_dev || !s->out_dev)) return fail(MAV_ERR_ARG, "mav_frame_step: detect needs a flow, par_dev and out_dev");
+    if (s->detect && s->gt_dev && (!s->mask_fixed_dev || !s->mask_dyn_dev)) return fail(MAV_ERR_ARG, "mav_frame_step: the counts need both masks");
+    if (s->n_bgr && (!s->bgr_dev || !s->gray_dev)) return fail(MAV_ERR_ARG, "mav_frame_step: n_bgr without bgr_dev / gray_dev");
+    if (s->out_bytes && (!s->out_host || !s->out_dev)) return fail(MAV_ERR_ARG, "mav_frame_step: out_bytes without out_host / out_dev");
+    HIPCHK(hipSetDevice(c->device));
+    for (int i = 0; i < s->n_wait_before; i++)
+        if (s->wait_before[i]) HIPCHK(hipEventSynchronize((hipEvent_t)s->wait_before[i]));
+    if (s->par_bytes) {
+        if (!s->par_host || !s->par_dev) return fail(MAV_ERR_ARG, "mav_frame_step: par_bytes without par_host / par_dev");
+        CHK(mav_upload_async_unordered(c, s->par_dev, s->par_host, s->par_bytes));
+    }
+    for (int i = 0; i < s->n_gather; i++)
+        CHK(mav_upload_gather(c, s->gather[i].dst_dev, s->gather[i].src_host, s->gather[i].count, s->gather[i].bytes_each, MAV_GATHER_SOURCES_HELD));
+    CHK(mav_upload_fence(c));
+    if (s->n_bgr) CHK(mav_bgr2gray_dev(c, s->bgr_dev, s->n_bgr, s->gray_dev));
+    float* flow = s->flow_dev;
+    if (s->compute_flow) {
+        if (!flow) {                             // nobody wants to see the flow: the context's own buffer, as mav_process_batch_dev
+            if (!c->flow_ws) HIPCHK(hipMalloc(&c->flow_ws, sizeof(float) * 2 * c->n0 * c->max_batch));
+            flow = c->flow_ws;
+        }
+        CHK(mav_farneback_dev(c, s->prev_dev, s->next_dev, s->n, flow));
+    }
+    for (int i = 0; i < s->n_record_after_flow; i++)
+        if (s->record_after_flow[i]) HIPCHK(hipEventRecord((hipEvent_t)s->record_after_flow[i], c->stream));
+    if (s->detect) {
+        const char* par = (const char*)s->par_dev;
+        CHK(mav_detect_dev(c, flow, (const uint32_t*)(par + s->off_samples), s->has_omega ? (const double*)(par + s->off_omega) : nullptr,
+                           s->has_omega ? (const double*)(par + s->off_dt) : nullptr, s->has_frame0 ? (const uint8_t*)(par + s->off_frame0) : nullptr,
+                           s->sky_dev, s->n, &s->foe, &s->thr, nullptr, s->mask_fixed_dev, s->mask_dyn_dev, (mav_result*)s->out_dev));
+        if (s->gt_dev)
+            CHK(mav_tpr_fpr_counts_dev(c, s->gt_dev, s->gt_images, s->mask_fixed_dev, s->mask_dyn_dev, 255, s->n,
+                                       (int64_t*)((char*)s->out_dev + s->off_counts_fixed), (int64_t*)((char*)s->out_dev + s->off_counts_dyn)));
+    }
+    if (s->out_bytes) CHK(mav_download_async(c, s->out_host, s->out_dev, s->out_bytes));
+    if (s->record_done) HIPCHK(hipEventRecord((hipEvent_t)s->record_done, c->stream));
+    return MAV_OK;
+}
+
+extern "C" int mav_frame_step_dev(mav_ctx* c, const mav_frame_step* s)
+{
+    if (!c || !s) return fail(MAV_ERR_ARG, "mav_frame_step_dev: NULL argument");
+    CHK(mav_worker_drain(c));
+    return frame_step_enqueue(c, s);
+}
+
+// The worker: one thread per context that has been posted to.  A context is single-threaded; while steps are posted the worker IS
+// that thread (the poster touches nothing of the context but this queue).  Three lanes = three workers enqueueing side by side
+// while the loop's own thread draws samples and fills in FrameResults.
+struct StepJob {
+    mav_frame_step s;
+    std::vector<const void*> src[MAV_STEP_MAX_GATHER];
+    std::vector<void*> wait_before, record_after;
+    uint64_t ticket = 0;
+};
+struct Worker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv_job, cv_done;
+    std::deque<StepJob> q;
+    uint64_t posted = 0, done = 0;
+    bool stop = false;
+    int first_rc = MAV_OK;                                     // first failure since the last drain
+    std::string first_err;
+    std::map<uint64_t, std::pair<int, std::string>> failed;   // by ticket, until somebody waits for it
+};
+static void worker_main(mav_ctx* c)
+{
+    Worker* w = c->worker;
+    (void)hipSetDevice(c->device);
+    std::unique_lock<std::mutex> lk(w->m);
+    for (;;) {
+        w->cv_job.wait(lk, [&] { return w->stop || !w->q.empty(); });
+        if (w->q.empty()) return;                              // stop, and nothing left to enqueue
+        StepJob job = std::move(w->q.front());
+        w->q.pop_front();
+        lk.unlock();
+        const int rc = frame_step_enqueue(c, &job.s);
+        lk.lock();
+        if (rc != MAV_OK) {
+            w->failed[job.ticket] = {rc, g_err};
+            if (w->first_rc == MAV_OK) { w->first_rc = rc; w->first_err = g_err; }
+        }
+        w->done = job.ticket;
+        w->cv_done.notify_all();
+    }
+}
+static void stop_worker(mav_ctx* c)
+{
+    if (!c->worker) return;
+    { std::lock_guard<std::mutex> lk(c->worker->m); c->worker->stop = true; }
+    c->worker->cv_job.notify_all();
+    c->worker->th.join();
+    delete c->worker;
+    c->worker = nullptr;
+}
+extern "C" int mav_frame_step_post(mav_ctx* c, const mav_frame_step* s, uint64_t* ticket)
+{
+    if (!c || !s || !ticket) return fail(MAV_ERR_ARG, "mav_frame_step_post: NULL argument");
+    if (s->n_gather < 0 || s->n_gather > MAV_STEP_MAX_GATHER || s->n_wait_before < 0 || s->n_record_after_flow < 0)
+        return fail(MAV_ERR_ARG, "mav_frame_step_post: list length out of range");
+    if (!c->worker) {
+        c->worker = new Worker();
+        c->worker->th = std::thread(worker_main, c);
+    }
+    Worker* w = c->worker;
+    StepJob job;
+    job.s = *s;
+    for (int i = 0; i < s->n_gather; i++) {
+        if (s->gather[i].count < 1 || !s->gather[i].src_host) return fail(MAV_ERR_ARG, "mav_frame_step_post: gather list %d is empty", i);
+        job.src[i].assign(s->gather[i].src_host, s->gather[i].src_host + s->gather[i].count);
+        job.s.gather[i].src_host = job.src[i].data();          // (heap blocks: they keep their address when the job moves)
+    }
+    if (s->n_wait_before) { job.wait_before.assign(s->wait_before, s->wait_before + s->n_wait_before); job.s.wait_before = job.wait_before.data(); }
+    if (s->n_record_after_flow) {
+        job.record_after.assign(s->record_after_flow, s->record_after_flow + s->n_record_after_flow);
+        job.s.record_after_flow = job.record_after.data();
+    }
+    {
+        std::lock_guard<std::mutex> lk(w->m);
+        job.ticket = *ticket = ++w->posted;
+        w->q.push_back(std::move(job));
+    }
+    w->cv_job.notify_one();
+    return MAV_OK;
+}
+extern "C" int mav_frame_step_wait(mav_ctx* c, uint64_t ticket, void* marker)
+{
+    if (!c) return fail(MAV_ERR_ARG, "mav_frame_step_wait: NULL context");
+    Worker* w = c->worker;
+    if (!w || ticket == 0) return fail(MAV_ERR_ARG, "mav_frame_step_wait: no such ticket");
+    {
+        std::unique_lock<std::mutex> lk(w->m);
+        if (ticket > w->posted) return fail(MAV_ERR_ARG, "mav_frame_step_wait: ticket %llu was never posted", (unsigned long long)ticket);
+        w->cv_done.wait(lk, [&] { return w->done >= ticket; });
+        auto it = w->failed.find(ticket);
+        if (it != w->failed.end()) {
+            const int rc = it->second.first;
+            g_err = it->second.second;
+            w->failed.erase(it);
+            return rc;
+        }
+    }
+    if (marker) HIPCHK(hipEventSynchronize((hipEvent_t)marker));
+    return MAV_OK;
+}
+extern "C" int mav_worker_drain(mav_ctx* c)
+{
+    if (!c) return fail(MAV_ERR_ARG, "mav_worker_drain: NULL context");
+    Worker* w = c->worker;
+    if (!w) return MAV_OK;
+    std::unique_lock<std::mutex> lk(w->m);
+    w->cv_done.wait(lk, [&] { return w->done == w->posted; });
+    const int rc = w->first_rc;
+    if (rc != MAV_OK) g_err = w->first_err;
+    w->first_rc = MAV_OK;
+    return rc;
 }
 
 // ---- host-pointer wrappers -----------------------------------------------------------------------------------

@@ -53,7 +53,34 @@ EXPORTS = [
     "mav_membw_probe", "mav_runtime_info", "mav_upload_async_unordered", "mav_mem_info", "mav_profile_intervals",
     "mav_upload_gather", "mav_download_async", "mav_marker_create", "mav_marker_record", "mav_marker_wait", "mav_marker_destroy",
     "mav_tpr_fpr_counts_dev", "mav_bgr2gray_dev", "mav_png_unfilter", "mav_comm_count",
+    "mav_marker_query", "mav_frame_step_dev", "mav_frame_step_post", "mav_frame_step_wait", "mav_worker_drain",
 ]
+
+GATHER_ORDERED, GATHER_SOURCES_HELD = 1, 2      # mav_upload_gather flags
+STEP_MAX_GATHER = 4
+
+
+class Gather(C.Structure):
+    _fields_ = [("src_host", C.POINTER(C.c_void_p)), ("count", C.c_int), ("bytes_each", C.c_size_t), ("dst_dev", C.c_void_p)]
+
+
+class FrameStep(C.Structure):
+    """mav_frame_step (include/mavflow.h): one iteration of the reference's loop as one call."""
+    _fields_ = [("n", C.c_int),
+                ("wait_before", C.POINTER(C.c_void_p)), ("n_wait_before", C.c_int),
+                ("par_host", C.c_void_p), ("par_dev", C.c_void_p), ("par_bytes", C.c_size_t),
+                ("gather", Gather * STEP_MAX_GATHER), ("n_gather", C.c_int),
+                ("bgr_dev", C.c_void_p), ("n_bgr", C.c_int), ("gray_dev", C.c_void_p),
+                ("compute_flow", C.c_int), ("prev_dev", C.c_void_p), ("next_dev", C.c_void_p), ("flow_dev", C.c_void_p),
+                ("record_after_flow", C.POINTER(C.c_void_p)), ("n_record_after_flow", C.c_int),
+                ("detect", C.c_int),
+                ("off_samples", C.c_size_t), ("off_omega", C.c_size_t), ("off_dt", C.c_size_t), ("off_frame0", C.c_size_t),
+                ("has_omega", C.c_int), ("has_frame0", C.c_int),
+                ("sky_dev", C.c_void_p), ("gt_dev", C.c_void_p), ("gt_images", C.c_int),
+                ("foe", FoeParams), ("thr", ThrParams),
+                ("mask_fixed_dev", C.c_void_p), ("mask_dyn_dev", C.c_void_p), ("out_dev", C.c_void_p),
+                ("off_counts_fixed", C.c_size_t), ("off_counts_dyn", C.c_size_t),
+                ("out_host", C.c_void_p), ("out_bytes", C.c_size_t), ("record_done", C.c_void_p)]
 
 _lib = None
 
@@ -135,6 +162,11 @@ def load(path: str | None = None) -> C.CDLL:
     lib.mav_marker_record.argtypes = [vp, vp]
     lib.mav_marker_wait.argtypes = [vp, vp]
     lib.mav_marker_destroy.argtypes = [vp, vp]
+    lib.mav_marker_query.argtypes = [vp, vp, C.POINTER(C.c_int)]
+    lib.mav_frame_step_dev.argtypes = [vp, C.POINTER(FrameStep)]
+    lib.mav_frame_step_post.argtypes = [vp, C.POINTER(FrameStep), C.POINTER(C.c_uint64)]
+    lib.mav_frame_step_wait.argtypes = [vp, C.c_uint64, vp]
+    lib.mav_worker_drain.argtypes = [vp]
     lib.mav_tpr_fpr_counts_dev.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp]
     lib.mav_bgr2gray_dev.argtypes = [vp, vp, C.c_int, vp]
     lib.mav_png_unfilter.argtypes = [vp, C.c_int, C.c_size_t, C.c_int, vp]
@@ -217,6 +249,28 @@ class _PinnedPool:
         self.idle_bytes = 0
         self.stamp = {}                                  # nbytes -> tick of the last use of that size (least recently used goes first)
         self.tick = 0
+        # A block that is the TARGET of a device -> host copy still enqueued (a retired DeviceArray, pipeline.py) must not be lent out
+        # again before that copy has landed, even if every array over it has been dropped: guard[ptr] = the marker recorded behind
+        # the copy; a returning block whose marker has not fired waits in `pending` (checked with mav_marker_query, never blocking).
+        self.guard = {}                                  # ptr -> marker object (has .done())
+        self.pending = []                                # [(marker, nbytes, ptr), ...]
+
+    def guard_until(self, arr: np.ndarray, marker) -> None:
+        """`arr` (from empty()) is being written by a copy that completes when `marker.done()`: keep its block out of circulation until then."""
+        base = arr
+        while isinstance(getattr(base, "base", None), np.ndarray):
+            base = base.base
+        self.guard[base.ctypes.data] = marker
+
+    def _reap(self) -> None:
+        if self.pending:
+            still = []
+            for marker, nbytes, ptr in self.pending:
+                if marker.done():
+                    self._shelve(nbytes, ptr)
+                else:
+                    still.append((marker, nbytes, ptr))
+            self.pending = still
 
     def empty(self, ctx: "Context", shape, dtype) -> np.ndarray:
         import weakref
@@ -224,6 +278,7 @@ class _PinnedPool:
         nbytes = max(1, int(np.prod(shape)) * dtype.itemsize)
         self.tick += 1
         self.stamp[nbytes] = self.tick
+        self._reap()
         lst = self.free.get(nbytes)
         if lst:
             ptr = lst.pop()
@@ -239,7 +294,15 @@ class _PinnedPool:
         return np.ctypeslib.as_array(owner).view(dtype)[:int(np.prod(shape))].reshape(shape)
 
     def _give(self, nbytes, ptr):
-        """A block comes back.  At most 4 idle blocks per size and CAP_BYTES idle in all: a long-running caller with changing batch
+        """A block comes back (the last array over it is gone) -- to the shelf, or, while a copy into it is still enqueued, to `pending`."""
+        marker = self.guard.pop(ptr, None)
+        if marker is not None and not marker.done():
+            self.pending.append((marker, nbytes, ptr))
+            return
+        self._shelve(nbytes, ptr)
+
+    def _shelve(self, nbytes, ptr):
+        """At most 4 idle blocks per size and CAP_BYTES idle in all: a long-running caller with changing batch
         sizes (a 64-pair 1080p flow block is 1 GB) must not pile up page-locked memory -- blocks of the least recently used sizes
         are released first, then the returning block itself if it alone exceeds the cap."""
         lst = self.free.setdefault(nbytes, [])
@@ -296,15 +359,47 @@ class Context:
         self.fb = fb if fb is not None else fb_defaults()
         h = C.c_void_p()
         check(self.lib.mav_create(C.byref(h), device, self.W, self.H, self.max_batch, C.byref(self.fb)))
-        self.h = h
+        self._h = h
+        self._posted = False                  # steps have been posted to the context's worker thread since the last drain
+
+    # A context is single-threaded.  Once a step has been posted (post_step) the library's worker thread is that thread until it has
+    # enqueued everything posted; `h` -- what every other call of this binding passes as the context -- therefore drains the worker
+    # first.  post_step / wait_step use the raw handle.
+    @property
+    def h(self):
+        if self._posted:
+            self.drain()
+        return self._h
+
+    @h.setter
+    def h(self, v):
+        self._h = v
+
+    def post_step(self, step: "FrameStep") -> int:
+        """mav_frame_step_post: hand one loop iteration to the context's worker thread; returns its ticket at once.  The caller keeps
+        the step's host buffers alive until wait_step(ticket, marker) has returned."""
+        t = C.c_uint64()
+        check(self.lib.mav_frame_step_post(self._h, C.byref(step), C.byref(t)))
+        self._posted = True
+        return t.value
+
+    def wait_step(self, ticket: int, marker=None) -> None:
+        """The step has been enqueued and, with its record_done marker given, has finished on the device; raises what the step raised."""
+        check(self.lib.mav_frame_step_wait(self._h, ticket, marker))
+
+    def drain(self) -> None:
+        """Every posted step has been enqueued (mav_worker_drain); raises the first failure among them."""
+        self._posted = False
+        check(self.lib.mav_worker_drain(self._h))
 
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "_h", None):
             for p in getattr(self, "_pinned", []):
-                self.lib.mav_host_free(self.h, p)
+                self.lib.mav_host_free(self._h, p)
             self._pinned = []
-            self.lib.mav_destroy(self.h)
-            self.h = None
+            self.lib.mav_destroy(self._h)            # (enqueues whatever was still posted, joins the worker)
+            self._h = None
+            self._posted = False
 
     def __del__(self):
         try:

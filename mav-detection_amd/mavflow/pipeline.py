@@ -35,13 +35,14 @@ class DeviceArray(np.lib.mixins.NDArrayOperatorsMixin):
     first time it is looked at, and -- so that a handle somebody still holds never goes stale -- by its owner right before the
     owner re-uses the memory (`_retire`).  After that it is an ordinary host array behind the same object."""
 
-    __slots__ = ("ctx", "ptr", "shape", "dtype", "_store_dtype", "_host", "_pending", "__weakref__")
+    __slots__ = ("ctx", "ptr", "shape", "dtype", "_store_dtype", "_host", "_pending", "_deferred", "__weakref__")
 
     def __init__(self, ctx: "_lib.Context", ptr: int, shape, dtype, store_dtype=None):
         self.ctx, self.ptr, self.shape, self.dtype = ctx, int(ptr), tuple(shape), np.dtype(dtype)
         self._store_dtype = np.dtype(store_dtype) if store_dtype is not None else self.dtype
         self._host = None
         self._pending = None                          # (page-locked block, _Marker): a copy to the host that has been enqueued
+        self._deferred = None                         # a flow FlowStage has not enqueued yet (_DeferredFlow): see FlowStage.flow_of
 
     @property
     def on_device(self) -> bool:
@@ -63,6 +64,8 @@ class DeviceArray(np.lib.mixins.NDArrayOperatorsMixin):
         return self.shape[0]
 
     def _materialize(self) -> np.ndarray:
+        if self._deferred is not None:                # nobody took the flow into a fused step: compute it now
+            self._deferred.flush()
         if self._host is None:
             if self._pending is not None:             # retired: the copy was enqueued, wait for it (and only for it)
                 buf, marker = self._pending
@@ -82,6 +85,8 @@ class DeviceArray(np.lib.mixins.NDArrayOperatorsMixin):
         owner records a marker behind the copies of all handles it retires (set through _retired_behind).  True if a copy was enqueued."""
         if self._host is not None or self._pending is not None:
             return False
+        if self._deferred is not None:
+            self._deferred.flush()
         buf = _lib._pinned.empty(self.ctx, self.shape, self._store_dtype)
         check(self.ctx.lib.mav_download_async(self.ctx.h, _lib._ptr(buf), self.ptr, buf.nbytes))
         self._pending = (buf, None)
@@ -135,7 +140,12 @@ class _Marker:
         check(ctx.lib.mav_marker_record(ctx.h, m))
 
     def wait(self) -> None:
-        check(self.ctx.lib.mav_marker_wait(self.ctx.h, self.m))
+        check(self.ctx.lib.mav_marker_wait(None, self.m))
+
+    def done(self) -> bool:
+        d = C.c_int(0)
+        check(self.ctx.lib.mav_marker_query(None, self.m, C.byref(d)))
+        return bool(d.value)
 
     def __del__(self):
         try:
@@ -156,6 +166,9 @@ def _retire_all(handles) -> None:
         marker = _Marker(moved[0].ctx)
         for h in moved:
             h._pending = (h._pending[0], marker)
+            # the page-locked block is the target of a copy that is only ENQUEUED: should the handle be dropped before the copy has
+            # landed, the pool must not lend the block to anybody else until the marker has fired
+            _lib._pinned.guard_until(h._pending[0], marker)
 
 
 def _as_frames(frames, H: int, W: int, name: str):
@@ -197,6 +210,17 @@ class _Fence:
         self.ctx.lib.mav_marker_destroy(None, self.m)
 
 
+class _DeferredFlow:
+    """A flow FlowStage has decided everything about -- frame slots, flow buffer -- but not enqueued: DetectPipeline.submit takes it
+    into ONE fused step (upload -> Farneback -> detection -> counts -> download: mav_frame_step) when the handle reaches it, and
+    anybody else who looks at the handle first gets it computed on the spot (flush)."""
+
+    __slots__ = ("stage", "frames", "slots", "prev_slot", "next_slot", "k", "handle", "bgr")
+
+    def flush(self) -> None:
+        self.stage._flush(self)
+
+
 class FlowStage:
     """cv2.calcOpticalFlowFarneback(prev, next, ...) (src/farneback.py:76-80) whose result stays where the next stage reads it.
     Frames are (H, W) u8 gray or (H, W, 3) u8 BGR as a capture hands them out; BGR frames are converted on the device
@@ -206,12 +230,17 @@ class FlowStage:
     2|3, a video advances one slot per frame), a new frame is copied into a slot as soon as the LAST flow that read that slot has
     finished -- two calls ago -- while the previous call's flow and whatever the caller enqueued behind it are still running; the flow
     fields alternate between two buffers the same way (DeviceArray handles of older calls are brought over before their buffer is
-    re-used)."""
+    re-used).
+
+    The flow is DEFERRED (round 6): flow_of / flow_next decide where everything goes and hand out the handle, but enqueue nothing.
+    When the handle reaches a DetectPipeline of the same context -- the reference's loop: get_flow_uv(i), then the detection on it --
+    the frames' upload, Farneback and the detection travel as one mav_frame_step; when somebody reads the handle first, or the next
+    flow is asked for, the flow is computed on the spot.  Same launches, same results either way."""
 
     RING = 4
 
-    def __init__(self, ctx: "_lib.Context"):
-        self.ctx = ctx
+    def __init__(self, ctx: "_lib.Context", defer: bool = True):
+        self.ctx, self.defer = ctx, bool(defer)
         n0 = ctx.W * ctx.H
         self._gray = ctx.alloc(self.RING * n0)
         self._gray_fence = [_Fence(ctx) for _ in range(self.RING)]
@@ -223,16 +252,20 @@ class FlowStage:
         self._pair_turn = 0
         self._have_prev = False                           # video mode (flow_next): slot of the previous frame
         self._prev_slot = 0
+        self._open: Optional[_DeferredFlow] = None        # the one flow that has been handed out but not enqueued
 
-    def _upload(self, frames, slots) -> None:
-        """frames[k] -> gray slot slots[k] of the ring."""
-        ctx, n0 = self.ctx, self.ctx.W * self.ctx.H
-        arrs = []
+    def _check_frames(self, frames):
+        ctx, arrs = self.ctx, []
         for k, f in enumerate(frames):
             a = np.asarray(f)
             if a.dtype != np.uint8 or a.shape[:2] != (ctx.H, ctx.W) or not (a.ndim == 2 or (a.ndim == 3 and a.shape[2] == 3)):
                 raise ValueError(f"frame {k}: expected ({ctx.H}, {ctx.W}) or ({ctx.H}, {ctx.W}, 3) uint8, got {a.shape} {a.dtype}")
             arrs.append(a if a.flags.c_contiguous else np.ascontiguousarray(a))
+        return arrs
+
+    def _upload(self, arrs, slots) -> None:
+        """arrs[k] (checked frames) -> gray slot slots[k] of the ring."""
+        ctx, n0 = self.ctx, self.ctx.W * self.ctx.H
         for sl in slots:
             self._gray_fence[sl].wait()
         gray = [(a, sl) for a, sl in zip(arrs, slots) if a.ndim == 2]
@@ -254,38 +287,134 @@ class FlowStage:
         if bgr:
             self._bgr_fence.record()
 
-    def _flow_into_next_buffer(self, prev_slot: int, next_slot: int) -> DeviceArray:
-        ctx, n0 = self.ctx, self.ctx.W * self.ctx.H
+    def _plan(self, arrs, slots, prev_slot: int, next_slot: int) -> DeviceArray:
+        """The next flow buffer for the flow prev_slot -> next_slot (arrs go to `slots` first); handles of the buffer's previous user
+        are brought over.  Returns the handle -- deferred, or enqueued at once when the stage does not defer."""
+        self._settle_open()
+        ctx = self.ctx
         k = self._turn
         self._turn ^= 1
         _retire_all(self._handles[k])
-        ctx.farneback_dev(self._gray.ptr + prev_slot * n0, self._gray.ptr + next_slot * n0, 1, self._flow[k].ptr)
-        for sl in (prev_slot, next_slot):
-            self._gray_fence[sl].record()
         h = DeviceArray(ctx, self._flow[k].ptr, (ctx.H, ctx.W, 2), np.float32)
         self._handles[k].append(weakref.ref(h))
+        d = _DeferredFlow()
+        d.stage, d.frames, d.slots, d.prev_slot, d.next_slot, d.k = self, arrs, list(slots), prev_slot, next_slot, k
+        d.bgr = bool(arrs) and arrs[0].ndim == 3
+        d.handle = weakref.ref(h)
+        # one fused step takes gray frames into CONSECUTIVE slots, or BGR frames (at most the two the staging holds) likewise
+        fusable = all(a.ndim == arrs[0].ndim for a in arrs) and all(slots[i + 1] == slots[i] + 1 for i in range(len(slots) - 1))
+        if self.defer and fusable:
+            h._deferred = d
+            self._open = d
+        else:
+            self._flush(d)
         return h
+
+    def _settle_open(self) -> None:
+        """Before the next flow is planned: the one handed out earlier that nobody has enqueued.  Its handle still held -> compute it;
+        handle gone -> nobody will read it, but in video mode its frame is the next pair's `prev`: the upload still happens."""
+        d = self._open
+        if d is None:
+            return
+        if d.handle() is not None:
+            self._flush(d)
+            return
+        self._open = None
+        if self._have_prev:
+            self._upload(d.frames, d.slots)
+        d.frames = None
+
+    def _flush(self, d: _DeferredFlow) -> None:
+        """Enqueue a planned flow through the plain calls (uploads, fence, Farneback, slot markers)."""
+        ctx, n0 = self.ctx, self.ctx.W * self.ctx.H
+        if self._open is d:
+            self._open = None
+        h = d.handle()
+        if h is not None:
+            h._deferred = None
+        self._upload(d.frames, d.slots)
+        ctx.farneback_dev(self._gray.ptr + d.prev_slot * n0, self._gray.ptr + d.next_slot * n0, 1, self._flow[d.k].ptr)
+        for sl in (d.prev_slot, d.next_slot):
+            self._gray_fence[sl].record()
+        d.frames = None
+
+    def _take(self, d: _DeferredFlow, step: "_lib.FrameStep", keep: list):
+        """Write the flow part of a fused step for the deferred flow `d` (called by DetectPipeline.submit, which posts the step): the
+        gather of its frames, BGR -> gray, Farneback, the markers.  Returns a callable to run once the step HAS been posted."""
+        ctx, n0 = self.ctx, self.ctx.W * self.ctx.H
+        nf = len(d.frames)
+        waits = [self._gray_fence[sl] for sl in d.slots if self._gray_fence[sl].armed]
+        records = [self._gray_fence[sl] for sl in dict.fromkeys((d.prev_slot, d.next_slot))]
+        g = step.gather[step.n_gather]
+        srcs = _ptr_array(d.frames)
+        keep.extend((srcs, d.frames))
+        g.src_host, g.count = C.cast(srcs, C.POINTER(C.c_void_p)), nf
+        if d.bgr:
+            if self._bgr is None:
+                self._bgr = ctx.alloc(6 * n0)
+            if self._bgr_fence.armed:
+                waits.append(self._bgr_fence)
+            records.append(self._bgr_fence)
+            g.bytes_each, g.dst_dev = 3 * n0, self._bgr.ptr
+            step.bgr_dev, step.n_bgr, step.gray_dev = self._bgr.ptr, nf, self._gray.ptr + d.slots[0] * n0
+        else:
+            g.bytes_each, g.dst_dev = n0, self._gray.ptr + d.slots[0] * n0
+        step.n_gather += 1
+        step.compute_flow = 1
+        step.prev_dev, step.next_dev = self._gray.ptr + d.prev_slot * n0, self._gray.ptr + d.next_slot * n0
+        step.flow_dev = self._flow[d.k].ptr
+        if waits:
+            wa = (C.c_void_p * len(waits))(*[f.m.value for f in waits])
+            keep.append(wa)
+            step.wait_before, step.n_wait_before = C.cast(wa, C.POINTER(C.c_void_p)), len(waits)
+        ra = (C.c_void_p * len(records))(*[f.m.value for f in records])
+        keep.append(ra)
+        step.record_after_flow, step.n_record_after_flow = C.cast(ra, C.POINTER(C.c_void_p)), len(records)
+
+        def posted():
+            for f in waits:
+                f.armed = False                      # the step waits for them before it overwrites the slots
+            for f in records:
+                f.armed = True
+            if self._open is d:
+                self._open = None
+            h = d.handle()
+            if h is not None:
+                h._deferred = None
+            d.frames = None
+        return posted
 
     def flow_of(self, prev: np.ndarray, nxt: np.ndarray) -> DeviceArray:
         """Flow prev -> next as a DeviceArray (H, W, 2) float32.  The handle stays valid: the buffer it points to is re-used by the
         call after the next one, which first brings a still-referenced handle over to the host."""
+        arrs = self._check_frames([prev, nxt])
         self._have_prev = False
         s0 = 2 * self._pair_turn
         self._pair_turn ^= 1
-        self._upload([prev, nxt], [s0, s0 + 1])
-        return self._flow_into_next_buffer(s0, s0 + 1)
+        return self._plan(arrs, [s0, s0 + 1], s0, s0 + 1)
 
     def flow_next(self, frame: np.ndarray) -> Optional[DeviceArray]:
         """Video mode, the reference's Farneback.process() (src/farneback.py:73-81): the flow from the previous frame handed in to this
         one; the previous frame's gray image is still on the device (the class's `prevgray`), so one frame crosses PCIe per step.
         None for the first frame."""
+        arrs = self._check_frames([frame])
         slot = (self._prev_slot + 1) % self.RING if self._have_prev else 0
-        self._upload([frame], [slot])
-        out = self._flow_into_next_buffer(self._prev_slot, slot) if self._have_prev else None
+        if self._have_prev:
+            out = self._plan(arrs, [slot], self._prev_slot, slot)
+        else:
+            self._settle_open()
+            self._upload(arrs, [slot])
+            out = None
         self._have_prev, self._prev_slot = True, slot
         return out
 
     def close(self):
+        self._open = None                                 # a flow nobody asked for is not computed
+        for hs in self._handles:
+            for wr in hs:
+                h = wr()
+                if h is not None and h._deferred is not None:
+                    h._deferred.flush()                   # ... unless its handle is still held: it stays readable
         for hs in self._handles:
             _retire_all(hs)
         if self.ctx.h:
@@ -306,12 +435,13 @@ class DetectPipeline:
 
     N_PAIRS = 1000                                        # focus_of_expansion.py:67
 
-    def __init__(self, ctx: "_lib.Context", batch: int, slots: int = 3, keep_flow: bool = False):
+    def __init__(self, ctx: "_lib.Context", batch: int, slots: int = 3, keep_flow: bool = False, worker: bool = True):
         """slots = 3: one batch computing, one being enqueued, and the one before still referenced by whoever holds its handles (the
-        loops keep the last finished frame's masks as attributes) -- its buffers are not needed yet, so nothing has to be brought over."""
+        loops keep the last finished frame's masks as attributes) -- its buffers are not needed yet, so nothing has to be brought over.
+        worker: submit() posts its step to the context's worker thread (mav_frame_step_post) instead of enqueueing it itself."""
         if batch > ctx.max_batch:
             raise ValueError(f"batch {batch} exceeds the context's max_batch {ctx.max_batch}")
-        self.ctx, self.B, self.keep_flow = ctx, int(batch), bool(keep_flow)
+        self.ctx, self.B, self.keep_flow, self.worker = ctx, int(batch), bool(keep_flow), bool(worker)
         self.n0 = ctx.W * ctx.H
         B, n0 = self.B, self.n0
         self._par_off = {}
@@ -327,6 +457,7 @@ class DetectPipeline:
             s.frames = None                                   # (2 B + 1) frames, allocated by the first submit that brings frames
             s.flow_in = None                                  # B flow fields, allocated by the first submit that brings host flow
             s.flow_out = ctx.alloc(8 * n0 * B) if keep_flow else None
+            s.ticket, s.keep = 0, None
             s.mf, s.md = ctx.alloc(n0 * B), ctx.alloc(n0 * B)
             s.par = ctx.alloc(self._par_bytes)
             s.out = ctx.alloc(self._out_bytes)
@@ -366,41 +497,49 @@ class DetectPipeline:
         self._shared[kind] = (img, buf, replicate, a)         # `a` kept: the id of `img` must not be recycled while cached
         return buf
 
-    def _per_pair_images(self, slot, attr: str, imgs, n: int) -> int:
+    # -- submit / collect -------------------------------------------------------------------------------------------------------
+    def _images(self, name: str, imgs, n: int):
+        """per-pair sky masks / ground-truth images as the reference hands them over -> checked u8 arrays"""
         arrs = []
         for k, m in enumerate(imgs):
             a = np.asarray(m)
             if a.shape != (self.ctx.H, self.ctx.W):
-                raise ValueError(f"{attr}[{k}]: expected ({self.ctx.H}, {self.ctx.W}), got {a.shape}")
+                raise ValueError(f"{name}[{k}]: expected ({self.ctx.H}, {self.ctx.W}), got {a.shape}")
             a = a.view(np.uint8) if a.dtype == np.bool_ else a
             if a.dtype != np.uint8:
-                raise ValueError(f"{attr}[{k}]: u8 or bool image expected, got {a.dtype}")
+                raise ValueError(f"{name}[{k}]: u8 or bool image expected, got {a.dtype}")
             arrs.append(a if a.flags.c_contiguous else np.ascontiguousarray(a))
         if len(arrs) != n:
-            raise ValueError(f"{attr}: {len(arrs)} images for {n} pairs")
-        buf = getattr(slot, attr)
-        if buf is None:
-            buf = self.ctx.alloc(self.n0 * self.B)
-            setattr(slot, attr, buf)
-        check(self.ctx.lib.mav_upload_gather(self.ctx.h, buf.ptr, _ptr_array(arrs), n, self.n0, 0))
-        return buf.ptr
+            raise ValueError(f"{name}: {len(arrs)} images for {n} pairs")
+        return arrs
 
-    # -- submit / collect -------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _add_gather(step, keep, arrays, bytes_each, dst_ptr) -> None:
+        srcs = _ptr_array(arrays)
+        keep.extend((srcs, arrays))
+        g = step.gather[step.n_gather]
+        g.src_host, g.count, g.bytes_each, g.dst_dev = C.cast(srcs, C.POINTER(C.c_void_p)), len(arrays), bytes_each, dst_ptr
+        step.n_gather += 1
+
     def submit(self, samples, prev: Optional[Sequence[np.ndarray]] = None, nxt: Optional[Sequence[np.ndarray]] = None, flow=None,
                omega=None, dt=None, frame0=None, sky=None, sky_shared=None, gt=None, gt_shared=None) -> int:
         """Enqueue one batch: frames (prev / nxt: one array per pair) or flow (a DeviceArray of this context, or float32 host arrays:
         one (H, W, 2) array per pair) -> FoE, masks, box records and, when a ground truth is given, the calculate_tpr_fpr counts of both
-        masks.  Returns the ticket for collect().  Nothing is waited for except the slot's own previous batch."""
+        masks.  Returns the ticket for collect().  Nothing is waited for except the slot's own previous batch.
+
+        The whole batch -- uploads, fence, Farneback (frames, or a flow FlowStage has deferred), detection, counts, result download,
+        marker -- is ONE mav_frame_step, posted to the context's worker thread (worker=True, the default: this thread goes on at once
+        and several lanes enqueue side by side) or enqueued by this thread in one call (worker=False)."""
         ctx, lib = self.ctx, self.ctx.lib
         H, W, n0 = ctx.H, ctx.W, self.n0
-        dev_flow = None
+        dev_flow = deferred = None
         if flow is not None and isinstance(flow, DeviceArray):
             if flow.ctx is not ctx:
                 raise ValueError("a DeviceArray flow must live on this pipeline's context")
             if flow.on_device:
                 if flow.shape != (H, W, 2) or flow.dtype != np.float32:
                     raise ValueError(f"flow: expected ({H}, {W}, 2) float32, got {flow.shape} {flow.dtype}")
-                dev_flow, n = flow.ptr, 1
+                dev_flow, n, deferred = flow.ptr, 1, flow._deferred
             else:
                 flow = [flow._materialize()]
         if dev_flow is None and flow is not None:
@@ -425,16 +564,30 @@ class DetectPipeline:
         for name, v, per in (("omega", omega, 3), ("dt", dt, 1), ("frame0", frame0, 1)):
             if v is not None and np.size(v) != n * per:
                 raise ValueError(f"{name}: expected {n * per} values, got {np.size(v)}")
+        sky_arrs = self._images("sky", sky, n) if (sky is not None and sky_shared is None) else None
+        gt_arrs = self._images("gt", gt, n) if (gt is not None and gt_shared is None) else None
+        # images shared by the whole run: uploaded once, ahead of everything (plain calls: they drain the worker the first time only)
+        sky_ptr = None
+        if sky_shared is not None:
+            if self._sky_any is None or self._sky_any[0] is not sky_shared:
+                self._sky_any = (sky_shared, bool(np.asarray(sky_shared).any()))
+            if self._sky_any[1]:                              # an all-False sky changes no mask: same result as no sky at all
+                sky_ptr = self._shared_image("sky", sky_shared, self.B).ptr
+        gt_ptr, gt_images = None, 0
+        if gt_shared is not None:
+            gt_ptr, gt_images = self._shared_image("gt", gt_shared, 1).ptr, 1
 
         # the arguments are in order: take the next slot (only now -- a refused call leaves the pipeline as it was)
         si = self._turn
         self._turn = (self._turn + 1) % len(self.slots)
         s = self.slots[si]
         if s.busy:                                            # its previous batch was never collected: finish it before the buffers go
-            check(lib.mav_marker_wait(ctx.h, s.marker))
-            s.busy = False
+            self._wait_slot(s)
         _retire_all(s.handles)
         s.n = n
+        step = _lib.FrameStep()
+        keep = []                                             # what the step reads on the host: alive until the slot's marker has fired
+        step.n = n
 
         # small per-pair parameters: packed into the slot's page-locked block, one asynchronous copy
         hp = s.h_par
@@ -448,68 +601,75 @@ class DetectPipeline:
             hp[o_dt:o_dt + n * 8].view(np.float64)[:] = 1.0 if dt is None else np.asarray(dt, np.float64).reshape(-1)
         if frame0 is not None:
             hp[o_f0:o_f0 + n] = np.asarray(frame0).reshape(-1).astype(np.uint8)
-        check(lib.mav_upload_async_unordered(ctx.h, s.par.ptr, _lib._ptr(hp), self._par_bytes))
+        step.par_host, step.par_dev, step.par_bytes = hp.ctypes.data, s.par.ptr, self._par_bytes
+        step.off_samples, step.off_omega, step.off_dt, step.off_frame0 = o, o_om, o_dt, o_f0
+        step.has_omega, step.has_frame0 = int(omega is not None), int(frame0 is not None)
 
         # frames / flow: gathered from the caller's arrays by the library's staging threads; this slot's buffers are idle (its
         # previous batch has been waited for), so the copies need no ordering against the batch that is computing now
-        flow_ptr = None
-        if dev_flow is not None:
-            flow_ptr = dev_flow
+        posted = None
+        s.flow_handle = None
+        if deferred is not None:                              # a flow FlowStage planned: its frames, Farneback and the detection in one step
+            posted = deferred.stage._take(deferred, step, keep)
+        elif dev_flow is not None:
+            step.flow_dev = dev_flow
         elif flow is not None:
             if s.flow_in is None:
                 s.flow_in = ctx.alloc(8 * n0 * self.B)
-            check(lib.mav_upload_gather(ctx.h, s.flow_in.ptr, _ptr_array(fl), n, 8 * n0, 0))
-            flow_ptr = s.flow_in.ptr
+            self._add_gather(step, keep, fl, 8 * n0, s.flow_in.ptr)
+            step.flow_dev = s.flow_in.ptr
         else:
             if s.frames is None:
                 s.frames = ctx.alloc((2 * self.B + 1) * n0)
             if n > 1 and all(q[k] is p[k + 1] for k in range(n - 1)):
                 # a video: pair k = (frame k, frame k + 1).  One run of n + 1 frames, next = prev + one frame: the library
                 # recognises the layout and blurs / expands every frame once (mav_farneback, "frame sequences")
-                check(lib.mav_upload_gather(ctx.h, s.frames.ptr, _ptr_array(p + [q[-1]]), n + 1, n0, 0))
-                prev_ptr, next_ptr = s.frames.ptr, s.frames.ptr + n0
+                self._add_gather(step, keep, p + [q[-1]], n0, s.frames.ptr)
+                step.prev_dev, step.next_dev = s.frames.ptr, s.frames.ptr + n0
             else:
-                check(lib.mav_upload_gather(ctx.h, s.frames.ptr, _ptr_array(p + q), 2 * n, n0, 0))
-                prev_ptr, next_ptr = s.frames.ptr, s.frames.ptr + n * n0
-        sky_ptr = None
-        if sky_shared is not None:
-            if self._sky_any is None or self._sky_any[0] is not sky_shared:
-                self._sky_any = (sky_shared, bool(np.asarray(sky_shared).any()))
-            if self._sky_any[1]:                              # an all-False sky changes no mask: same result as no sky at all
-                sky_ptr = self._shared_image("sky", sky_shared, self.B).ptr
-        elif sky is not None:
-            sky_ptr = self._per_pair_images(s, "sky", sky, n)
-        gt_ptr, gt_images = None, 0
-        if gt_shared is not None:
-            gt_ptr, gt_images = self._shared_image("gt", gt_shared, 1).ptr, 1
-        elif gt is not None:
-            gt_ptr, gt_images = self._per_pair_images(s, "gt", gt, n), n
-        check(lib.mav_upload_fence(ctx.h))
-
-        par = s.par.ptr
-        smp_ptr = par + self._par_off["samples"][0]
-        om_ptr = par + o_om if omega is not None else None
-        dt_ptr = par + o_dt if omega is not None else None
-        f0_ptr = par + o_f0 if frame0 is not None else None
-        res_ptr = s.out.ptr
-        if flow_ptr is None:
-            out_flow = s.flow_out.ptr if s.flow_out is not None else None
-            check(lib.mav_process_batch_dev(ctx.h, prev_ptr, next_ptr, smp_ptr, om_ptr, dt_ptr, f0_ptr, sky_ptr, n, C.byref(self.foe_params),
-                                            C.byref(self.thr_params), out_flow, None, s.mf.ptr, s.md.ptr, res_ptr))
-            s.flow_handle = None if out_flow is None else (out_flow, )
-        else:
-            check(lib.mav_detect_dev(ctx.h, flow_ptr, smp_ptr, om_ptr, dt_ptr, f0_ptr, sky_ptr, n, C.byref(self.foe_params),
-                                     C.byref(self.thr_params), None, s.mf.ptr, s.md.ptr, res_ptr))
-            s.flow_handle = None
+                self._add_gather(step, keep, p + q, n0, s.frames.ptr)
+                step.prev_dev, step.next_dev = s.frames.ptr, s.frames.ptr + n * n0
+            step.compute_flow = 1
+            if s.flow_out is not None:                        # (else: the context's own flow buffer, which no handle points into)
+                step.flow_dev = s.flow_out.ptr
+                s.flow_handle = (s.flow_out.ptr, )
+        for attr, arrs in (("sky", sky_arrs), ("gt", gt_arrs)):
+            if arrs is not None:
+                buf = getattr(s, attr)
+                if buf is None:
+                    buf = ctx.alloc(n0 * self.B)
+                    setattr(s, attr, buf)
+                self._add_gather(step, keep, arrs, n0, buf.ptr)
+                if attr == "sky":
+                    sky_ptr = buf.ptr
+                else:
+                    gt_ptr, gt_images = buf.ptr, n
+        step.detect = 1
+        step.sky_dev, step.gt_dev, step.gt_images = sky_ptr, gt_ptr, gt_images
+        step.foe, step.thr = self.foe_params, self.thr_params
+        step.mask_fixed_dev, step.mask_dyn_dev, step.out_dev = s.mf.ptr, s.md.ptr, s.out.ptr
+        step.off_counts_fixed, step.off_counts_dyn = self.B * 32, 2 * self.B * 32
         s.has_counts = gt_ptr is not None
-        nout = n * 32
-        if s.has_counts:
-            check(lib.mav_tpr_fpr_counts_dev(ctx.h, gt_ptr, gt_images, s.mf.ptr, s.md.ptr, 255, n, res_ptr + self.B * 32, res_ptr + 2 * self.B * 32))
-            nout = self._out_bytes
-        check(lib.mav_download_async(ctx.h, _lib._ptr(s.h_out), res_ptr, nout))
-        check(lib.mav_marker_record(ctx.h, s.marker))
+        step.out_host, step.out_bytes = s.h_out.ctypes.data, (self._out_bytes if s.has_counts else n * 32)
+        step.record_done = s.marker
+        if self.worker:
+            s.ticket = ctx.post_step(step)
+        else:
+            s.ticket = 0
+            check(lib.mav_frame_step_dev(ctx.h, C.byref(step)))
+        if posted is not None:
+            posted()
+        s.keep = keep
         s.busy = True
         return si
+
+    def _wait_slot(self, s) -> None:
+        if s.ticket:
+            self.ctx.wait_step(s.ticket, s.marker)
+        else:
+            check(self.ctx.lib.mav_marker_wait(None, s.marker))
+        s.busy = False
+        s.keep = None
 
     def collect(self, ticket: int) -> dict:
         """Wait for that batch (and only that batch) and return its records (n,) RESULT_DTYPE, the (n, 4) int64 counts of both masks
@@ -519,8 +679,7 @@ class DetectPipeline:
         if not s.busy:
             raise ValueError("this ticket has been collected already")
         ctx = self.ctx
-        check(ctx.lib.mav_marker_wait(ctx.h, s.marker))
-        s.busy = False
+        self._wait_slot(s)
         n, B = s.n, self.B
         res = s.h_out[:n * 32].view(_lib.RESULT_DTYPE).copy()
         cf = cd = None
@@ -543,8 +702,10 @@ class DetectPipeline:
             return
         for s in self.slots:
             if s.busy:
-                ctx.lib.mav_marker_wait(ctx.h, s.marker)
-                s.busy = False
+                try:
+                    self._wait_slot(s)
+                except Exception:                             # noqa: BLE001 -- a failed step must not keep the buffers from going
+                    s.busy = False
             _retire_all(s.handles)
         ctx.sync()
         for s in self.slots:

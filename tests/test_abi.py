@@ -93,3 +93,30 @@ def test_no_environment_override_of_the_library_path(mav, monkeypatch):
     src = open(_lib.__file__).read()
     assert "os.environ" not in src and "getenv" not in src
     assert _lib.SO_PATH.endswith(os.path.join("mavflow", "libmavflow.so"))
+
+
+def test_frame_step_struct_layout_matches_the_header(mav, tmp_path):
+    """mav_frame_step / mav_gather (include/mavflow.h) against their ctypes mirrors, field by field: offsets from a C program compiled
+    against the header here and now."""
+    import shutil
+    import subprocess
+    from mavflow import _lib
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no C compiler")
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "mavflow.h"', "int main(void) {"]
+    for cname, cls in (("mav_frame_step", _lib.FrameStep), ("mav_gather", _lib.Gather)):
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for name, _ in cls._fields_:
+            lines.append(f'  printf("{cname}.{name} %zu\\n", offsetof({cname}, {name}));')
+    lines.append("  return 0; }")
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call([cc, "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, cls in (("mav_frame_step", _lib.FrameStep), ("mav_gather", _lib.Gather)):
+        assert int(got[cname]) == C.sizeof(cls)
+        for name, _ in cls._fields_:
+            assert int(got[f"{cname}.{name}"]) == getattr(cls, name).offset, (cname, name)
+    assert _lib.STEP_MAX_GATHER == 4 and (_lib.GATHER_ORDERED, _lib.GATHER_SOURCES_HELD) == (1, 2)

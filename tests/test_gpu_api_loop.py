@@ -469,3 +469,214 @@ def test_a_seam_that_hides_its_lanes_is_followed_anyway(mav):
         p.release()
     for i in range(N - 1):
         assert vars(res["run_detection"][i]) == vars(res["run_detection_staged"][i]), i
+
+
+# ---- round 6: one loop iteration as ONE call (mav_frame_step), the contexts' worker threads, deferred flow ------------------------------
+def _same_outputs(a, b, tag):
+    assert a["results"].tobytes() == b["results"].tobytes(), tag
+    n = len(a["mask_fixed"])
+    for k in range(n):
+        assert np.array_equal(np.asarray(a["mask_fixed"][k]), np.asarray(b["mask_fixed"][k])), (tag, k)
+        assert np.array_equal(np.asarray(a["mask_dyn"][k]), np.asarray(b["mask_dyn"][k])), (tag, k)
+    for key in ("counts_fixed", "counts_dyn"):
+        assert (a[key] is None) == (b[key] is None) and (a[key] is None or np.array_equal(a[key], b[key])), (tag, key)
+
+
+def test_frame_step_posted_inline_and_plain_calls_agree(mav):
+    """Every way a batch can reach the detection -- frames, a video run, a host flow field, a deferred Farneback flow (gray and BGR
+    frames, pair mode and video mode) -- through the fused step posted to the worker thread, the same step enqueued by the calling
+    thread, and the plain synchronous call: identical records, masks and counts."""
+    from mavflow import _lib
+    from mavflow.pipeline import DetectPipeline, FlowStage
+    W, H, B = 256, 192, 3
+    seq = synth.make_sequence(W, H, B + 2)
+    frames = [np.ascontiguousarray(seq[k]) for k in range(B + 2)]
+    prev, nxt = synth.make_batch(W, H, B, distinct=B)
+    smp = np.stack([synth.foe_samples(W, H, b) for b in range(B)])
+    rng = np.random.default_rng(5)
+    gts = [(rng.integers(0, 2, (H, W)) * 255).astype(np.uint8) for _ in range(B)]
+    skies = [np.zeros((H, W), bool) for _ in range(B)]
+    for k, sk in enumerate(skies):
+        sk[:20 + 7 * k] = True
+    omega, dts = np.tile([0.01, -0.02, 0.005], (B, 1)) / 0.04, np.full(B, 0.04)
+    f0 = [True] + [False] * (B - 1)
+    with _lib.Context(W, H, B) as ctx:
+        ref = ctx.process_batch(prev, nxt, smp, omega=omega, dt=dts, frame0=f0, sky=np.stack(skies))
+        ref_counts = [np.stack([ctx.tpr_fpr_counts(gts[k], ref[m][k:k + 1].view(np.uint8), 255)[0] for k in range(B)]) for m in ("mask_fixed", "mask_dyn")]
+        ref_vid = ctx.process_batch(seq[:B].copy(), seq[1:B + 1].copy(), smp)
+        flows = ctx.farneback(prev, nxt)
+    outs = {}
+    for worker in (True, False):
+        with _lib.Context(W, H, B) as ctx:
+            pipe = DetectPipeline(ctx, B, worker=worker)
+            o = pipe.collect(pipe.submit(smp, prev=list(prev), nxt=list(nxt), omega=omega, dt=dts, frame0=f0, sky=skies, gt=gts))
+            assert o["results"].tobytes() == ref["results"].tobytes() and np.array_equal(o["counts_fixed"], ref_counts[0]) and np.array_equal(o["counts_dyn"], ref_counts[1])
+            for k in range(B):
+                assert np.array_equal(o["mask_fixed"][k], ref["mask_fixed"][k]) and np.array_equal(o["mask_dyn"][k], ref["mask_dyn"][k])
+            v = pipe.collect(pipe.submit(smp, prev=frames[:B], nxt=frames[1:B + 1]))                       # a video: one run of B + 1 frames
+            assert v["results"].tobytes() == ref_vid["results"].tobytes()
+            hf = pipe.collect(pipe.submit(smp, flow=[flows[b] for b in range(B)], omega=omega, dt=dts, frame0=f0, sky=skies, gt_shared=gts[0]))
+            assert hf["results"].tobytes() == ref["results"].tobytes()
+            outs[worker] = (o, v, hf)
+            pipe.close()
+    for a, b, tag in zip(outs[True], outs[False], ("frames", "video", "host flow")):
+        _same_outputs(a, b, tag)
+    # deferred flow: FlowStage hands out a handle, the pipeline of the same context takes upload + Farneback + detection as one step
+    bgr = [np.repeat(f[..., None], 3, axis=2) for f in frames]                                                # gray values replicated: same luma
+    for worker in (True, False):
+        with _lib.Context(W, H, 1) as ctx:
+            ref1 = [ctx.process_batch(seq[k:k + 1].copy(), seq[k + 1:k + 2].copy(), smp[k:k + 1]) for k in range(B)]
+            stage, pipe = FlowStage(ctx), DetectPipeline(ctx, 1, worker=worker)
+            for mode in ("pairs", "video", "bgr pairs", "bgr video"):
+                src = bgr if mode.startswith("bgr") else frames
+                if mode.endswith("video"):
+                    stage._have_prev = False
+                    assert stage.flow_next(src[0]) is None
+                got = []
+                for k in range(B):
+                    h = stage.flow_of(src[k], src[k + 1]) if mode.endswith("pairs") else stage.flow_next(src[k + 1])
+                    assert h._deferred is not None and h.on_device
+                    t = pipe.submit(smp[k], flow=h)
+                    assert h._deferred is None and stage._open is None
+                    got.append((pipe.collect(t), h))
+                for k in range(B):
+                    assert got[k][0]["results"].tobytes() == ref1[k]["results"].tobytes(), (worker, mode, k)
+                    assert np.array_equal(got[k][0]["mask_fixed"][0], ref1[k]["mask_fixed"][0]), (worker, mode, k)
+                    assert np.array_equal(np.asarray(got[k][1]), ref1[k]["flow"][0]), (worker, mode, k)   # the handle reads the flow the step computed
+            pipe.close(); stage.close()
+
+
+def test_deferred_flow_is_computed_when_somebody_looks_first(mav):
+    """A deferred handle that is read, kept across later flows, or dropped unread -- before any pipeline sees it."""
+    from mavflow import _lib
+    from mavflow.pipeline import DetectPipeline, FlowStage
+    W, H = 256, 192
+    seq = synth.make_sequence(W, H, 6)
+    fr = [np.ascontiguousarray(f) for f in seq]
+    smp = synth.foe_samples(W, H, 0)
+    with _lib.Context(W, H, 1) as ctx:
+        ref = [ctx.farneback(seq[k:k + 1].copy(), seq[k + 1:k + 2].copy())[0] for k in range(5)]
+        stage = FlowStage(ctx)
+        h0 = stage.flow_of(fr[0], fr[1])
+        assert h0._deferred is not None
+        assert np.array_equal(np.asarray(h0), ref[0]) and h0._deferred is None          # read: computed on the spot
+        h1 = stage.flow_of(fr[1], fr[2])
+        h2 = stage.flow_of(fr[2], fr[3])                                                # the next plan settles the open one (h1 is held: computed)
+        assert h1._deferred is None and h2._deferred is not None
+        h3 = stage.flow_of(fr[3], fr[4])                                                # h1's buffer is re-used: h1 goes to the host first
+        assert not h1.on_device and np.array_equal(np.asarray(h1), ref[1]) and np.array_equal(np.asarray(h2), ref[2])
+        del h3                                                                          # dropped unread: never computed
+        stage.flow_next(fr[0])                                                          # video mode from here
+        a = stage.flow_next(fr[1])
+        del a                                                                           # dropped: its FRAME must still arrive (next pair's prev)
+        b = stage.flow_next(fr[2])
+        pipe = DetectPipeline(ctx, 1)
+        out = pipe.collect(pipe.submit(smp, flow=b))
+        assert np.array_equal(np.asarray(b), ref[1])
+        with _lib.Context(W, H, 1) as c2:
+            assert out["results"].tobytes() == c2.detect(ref[1][None], smp[None])["results"].tobytes()
+        pipe.close(); stage.close()
+        nodefer = FlowStage(ctx, defer=False)
+        assert nodefer.flow_of(fr[0], fr[1])._deferred is None
+        nodefer.close()
+
+
+def test_posted_step_errors_surface_at_wait_and_drain(mav):
+    from mavflow import _lib
+    W, H = 64, 48
+    with _lib.Context(W, H, 1) as ctx:
+        bad = _lib.FrameStep()
+        bad.n = 5                                              # beyond max_batch
+        t = ctx.post_step(bad)
+        with pytest.raises(ValueError, match="outside"):
+            ctx.wait_step(t)
+        ok = _lib.FrameStep()
+        ok.n = 1                                               # nothing to do: a legal empty step
+        t2 = ctx.post_step(ok)
+        ctx.wait_step(t2)
+        t3 = ctx.post_step(bad)
+        with pytest.raises(ValueError):
+            ctx.sync()                                         # any other call of the binding drains the worker first and reports
+        ctx.sync()
+        with pytest.raises(ValueError):
+            ctx.wait_step(t3)                                  # ... and the ticket still tells
+        with pytest.raises(ValueError):
+            ctx.wait_step(999)
+        with pytest.raises(ValueError):
+            _lib.check(ctx.lib.mav_frame_step_dev(ctx.h, C.byref(bad)))
+
+
+def test_upload_gather_reads_page_locked_sources_before_it_returns(mav):
+    """the header promises that on return every source has been read.  A page-locked source is overwritten right after
+    the call while the compute stream is still busy -- with the copy stream and with inline uploads (where the copy would sit behind
+    the compute stream's kernels) -- and the device must hold the ORIGINAL bytes.  With MAV_GATHER_SOURCES_HELD the caller keeps them."""
+    from mavflow import _lib
+    from mavflow.pipeline import _ptr_array
+    W, H, B = 640, 480, 8
+    prev, nxt = synth.make_batch(W, H, B, distinct=2)
+    rng = np.random.default_rng(3)
+    n = 4 << 20
+    for inline in (0, 1):
+        with _lib.Context(W, H, B) as ctx:
+            ctx.set_option("inline_uploads", inline)
+            dp, dn, df = ctx.alloc(prev.nbytes).upload(prev), ctx.alloc(nxt.nbytes).upload(nxt), ctx.alloc(8 * W * H * B)
+            src = ctx.pinned_like(rng.integers(0, 256, n, dtype=np.uint8))
+            page = rng.integers(0, 256, n, dtype=np.uint8)
+            want = np.stack([src.copy(), page.copy()])
+            dst = ctx.alloc(2 * n)
+            for flags in (0, _lib.GATHER_ORDERED):
+                src[:] = want[0]; page[:] = want[1]
+                ctx.sync()
+                for _ in range(3):
+                    ctx.farneback_dev(dp.ptr, dn.ptr, B, df.ptr)                         # ~10 ms of kernels ahead on the compute stream
+                _lib.check(ctx.lib.mav_upload_gather(ctx.h, dst.ptr, _ptr_array([src, page]), 2, n, flags))
+                src[:] = 0xAA; page[:] = 0x55                                            # the caller re-uses its buffers at once
+                ctx.upload_fence()
+                got = dst.download(np.uint8, (2, n))
+                assert np.array_equal(got, want), (inline, flags)
+            src[:] = want[0]
+            _lib.check(ctx.lib.mav_upload_gather(ctx.h, dst.ptr, _ptr_array([src]), 1, n, _lib.GATHER_SOURCES_HELD))
+            ctx.upload_fence(); ctx.sync()                                               # held until the work behind it has completed
+            assert np.array_equal(dst.download(np.uint8, (n,)), want[0])
+
+
+def test_retired_handles_dropped_at_once_do_not_leak_their_blocks_to_another_lane(mav):
+    """a retired handle's page-locked block is the target of a copy that is only ENQUEUED.  Drop the handle at once and
+    let another lane materialise same-size handles: nobody may be handed that block before the copy has landed.  Two lanes, many
+    rounds; every materialised mask is compared with a synchronous download of the same device memory."""
+    from mavflow import _lib
+    from mavflow.pipeline import DetectPipeline, _retire_all
+    W, H = 640, 480
+    prev, nxt = synth.make_batch(W, H, 2, distinct=2)
+    smp = np.stack([synth.foe_samples(W, H, b) for b in range(2)])
+    lanes = [_lib.Context(W, H, 1) for _ in range(2)]
+    for c in lanes:
+        c.set_option("inline_uploads", 1)
+    pipes = [DetectPipeline(c, 1, slots=2) for c in lanes]
+    pool = _lib._pinned
+    seen_pending = 0
+    for rnd in range(12):
+        a, b = rnd & 1, (rnd & 1) ^ 1
+        oa = pipes[a].collect(pipes[a].submit(smp[a], prev=[prev[a]], nxt=[nxt[a]]))
+        # lane a: a long batch behind which the retiring copies queue up, then retire lane a's handles and drop them immediately
+        t = pipes[a].submit(smp[a], prev=[prev[a]], nxt=[nxt[a]])
+        held = [oa["mask_fixed"][0], oa["mask_dyn"][0]]
+        refs = pipes[a].slots[0].handles + pipes[a].slots[1].handles
+        _retire_all([r for r in refs if r() is not None])
+        assert all(h._pending is not None for h in held)
+        del held, oa
+        seen_pending += len(pool.pending)
+        # lane b: same-size handles materialised right now -- they take blocks from the pool
+        ob = pipes[b].collect(pipes[b].submit(smp[b], prev=[prev[b]], nxt=[nxt[b]]))
+        for key, buf in (("mask_fixed", pipes[b].slots[(pipes[b]._turn - 1) % 2].mf), ("mask_dyn", pipes[b].slots[(pipes[b]._turn - 1) % 2].md)):
+            got = np.asarray(ob[key][0]).copy()
+            lanes[a].sync()                                                              # lane a's late copies land now (into blocks nobody else may hold)
+            sync = buf.download(np.uint8, (H, W)).view(np.bool_)
+            assert np.array_equal(got, sync) and np.array_equal(np.asarray(ob[key][0]), sync), (rnd, key)
+        pipes[a].collect(t)
+    assert seen_pending > 0, "the scenario never had a block waiting for its copy: the test did not exercise the guard"
+    for p in pipes:
+        p.close()
+    for c in lanes:
+        c.close()
+    assert not pool.guard or all(m.done() for m in pool.guard.values())
