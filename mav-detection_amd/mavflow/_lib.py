@@ -375,6 +375,11 @@ class Context:
     def h(self, v):
         self._h = v
 
+    @property
+    def alive(self) -> bool:
+        """Not closed (asks nothing of the worker thread, unlike `h`)."""
+        return bool(self._h)
+
     def post_step(self, step: "FrameStep") -> int:
         """mav_frame_step_post: hand one loop iteration to the context's worker thread; returns its ticket at once.  The caller keeps
         the step's host buffers alive until wait_step(ticket, marker) has returned."""

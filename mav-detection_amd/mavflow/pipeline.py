@@ -72,7 +72,7 @@ class DeviceArray(np.lib.mixins.NDArrayOperatorsMixin):
                 marker.wait()
                 self._pending = None
             else:
-                if not self.ctx.h:
+                if not self.ctx.alive:
                     raise _lib.MavflowError("the context that holds this array has been closed")
                 buf = _lib._pinned.empty(self.ctx, self.shape, self._store_dtype)
                 check(self.ctx.lib.mav_memcpy_d2h(self.ctx.h, _lib._ptr(buf), self.ptr, buf.nbytes))
@@ -417,7 +417,7 @@ class FlowStage:
                     h._deferred.flush()                   # ... unless its handle is still held: it stays readable
         for hs in self._handles:
             _retire_all(hs)
-        if self.ctx.h:
+        if self.ctx.alive:
             self.ctx.sync()                               # the copies of retired handles have landed before the buffers go
         for b in [self._gray, self._bgr] + self._flow:
             if b is not None:
@@ -698,7 +698,7 @@ class DetectPipeline:
 
     def close(self):
         ctx = self.ctx
-        if not ctx.h:
+        if not ctx.alive:
             return
         for s in self.slots:
             if s.busy:
@@ -727,10 +727,15 @@ class DetectPipeline:
 # Measured (tools/lanes_probe.py, one pair per call, ms per pair with 1 / 2 / 3 contexts): 1280x720 0.299 / 0.207 / 0.181,
 # 1920x1080 0.523 / 0.429 / 0.458, 640x480 0.207 / 0.124 / 0.101 (one stream per lane: _one_stream_per_lane).  Beyond ~200 MB of sweep working set per call the chains fight over
 # the 256 MB Infinity Cache and a second lane loses (a 64-pair batch already keeps two pairs in flight inside its one context).
-def auto_lanes(W: int, H: int, batch: int = 1) -> int:
-    """Contexts a stream of `batch`-pair calls at this frame size is spread over: 3 up to 100 MB of finest-layer sweep working set per
-    call (80 B per pixel and pair), 2 up to 200 MB (one 1080p pair: 166 MB), 1 beyond."""
+def auto_lanes(W: int, H: int, batch: int = 1, uploads: bool = True) -> int:
+    """Contexts a stream of `batch`-pair calls at this frame size is spread over.  Device-resident inputs (uploads=False): 3 up to
+    100 MB of finest-layer sweep working set per call (80 B per pixel and pair), 2 up to 200 MB (one 1080p pair: 166 MB), 1 beyond.
+    With the frames crossing PCIe inside every call (the reference-shaped loops: a lane's upload sits on its one stream, in front of
+    its chain) a third lane fills those gaps up to 200 MB as well: one-frame loop at 1080p 0.47 ms per frame with two lanes, 0.45
+    with three (profiles/r06/api_loop_host_split.txt)."""
     ws = 80 * W * H * batch
+    if uploads:
+        return 3 if ws <= (200 << 20) else 1
     return 3 if ws <= (100 << 20) else (2 if ws <= (200 << 20) else 1)
 
 

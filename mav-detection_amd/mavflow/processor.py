@@ -188,7 +188,7 @@ class Processor:
         """The (cached) pipeline over these contexts for `batch` pairs per submit."""
         key = (tuple(id(c) for c in ctxs), batch)
         pipe = self._pipes.get(key)
-        if pipe is None or any(a is not b or not b.h for a, b in zip(pipe.ctxs, ctxs)):
+        if pipe is None or any(a is not b or not b.alive for a, b in zip(pipe.ctxs, ctxs)):
             if pipe is not None:
                 pipe.close()
             pipe = pipeline.LanedPipeline(ctxs, batch)
@@ -199,7 +199,7 @@ class Processor:
     def _own_ctxs(self, batch: int = 1, lanes: int = 1):
         """This loop's own contexts (never the helpers' shared, evictable ones): `lanes` of them, each for `batch` pairs."""
         W, H = self.dataset.capture_size
-        ok = len(self._ctxs) >= lanes and all(c.h and c.max_batch >= batch and (c.W, c.H) == (W, H) for c in self._ctxs[:lanes])
+        ok = len(self._ctxs) >= lanes and all(c.alive and c.max_batch >= batch and (c.W, c.H) == (W, H) for c in self._ctxs[:lanes])
         if not ok:
             self._close_pipes()
             for c in self._ctxs:
@@ -216,7 +216,7 @@ class Processor:
                 return [s.ctx for s in st.stages]
         # a seam that does not show its stage: the contexts its handles have come from so far (a seam that takes two or three contexts
         # in turn is recognised within its first frames; the pipeline is then rebuilt once over all of them)
-        self._lane_seen = [c for c in getattr(self, "_lane_seen", []) if c.h]
+        self._lane_seen = [c for c in getattr(self, "_lane_seen", []) if c.alive]
         if not any(c is flow.ctx for c in self._lane_seen):
             self._lane_seen.append(flow.ctx)
         return list(self._lane_seen)
@@ -325,7 +325,7 @@ class Processor:
         total_mask are DeviceArray handles (read them and they are host arrays).  Frame 0 takes the reference's float32 path
         (detector.py:80-81).  The sample coordinates are drawn from np.random exactly where get_FOE_dense draws them.
         Software-pipelined: frame i's FrameResult is filled in (and its JSON written) after the following frames -- as many as the
-        pipeline has lanes (pipeline.auto_lanes: 2 - 3 contexts taken in turn for frames up to 1080p, whose one-pair chains of launches
+        pipeline has lanes (pipeline.auto_lanes: 3 contexts taken in turn for frames up to 1080p, whose one-pair chains of launches
         then interleave on the GPU) -- have been enqueued; results, files and their order are those of the plain loop."""
         from collections import deque
         pending = deque()

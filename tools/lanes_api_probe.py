@@ -25,8 +25,8 @@ for rep in range(REPS):
         p, ds = procs[lanes]
         p.frame_index = 0; p.detection_results = {}; p.config.results = {}
         np.random.seed(7)
-        t0 = time.perf_counter(); p.run_detection(); dt = time.perf_counter() - t0
-        row.append(f"lanes {lanes}: {1e3 * dt / F:.4f}")
+        c0 = time.thread_time(); t0 = time.perf_counter(); p.run_detection(); dt = time.perf_counter() - t0; cpu = time.thread_time() - c0
+        row.append(f"lanes {lanes}: {1e3 * dt / F:.4f} (loop thread busy {1e3 * cpu / F:.4f})")
     print(f"{W}x{H}, {F} frames, ms per frame   " + "   ".join(row), flush=True)
 for p, ds in procs.values():
     p.release()
