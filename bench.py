@@ -25,11 +25,28 @@ for p in (ROOT, os.path.join(ROOT, "mav-detection_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+
+def _cgroup_cores():
+    """Host cores the cgroup's CPU-time quota amounts to (None: no quota)."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if quota == "max" else max(1, int(float(quota) / float(period) + 0.5))
+    except (OSError, ValueError):
+        return None
+
+
+# numpy's BLAS starts one thread per core it can SEE (64 on the 256-core GPU hosts) and its idle threads spin for tens of ms after a
+# matrix product; inside a cgroup with a CPU-time quota (16 cores per 100 ms here) the spinners burn the quota and the kernel freezes
+# every thread of the process until the period ends: 25 - 80 ms stalls in whatever runs next (profiles/r06/stall_bisect.txt).  Half
+# the granted cores at most, set before numpy is imported.
+for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, str(max(1, (_cgroup_cores() or (os.cpu_count() or 2)) // 2)))
+
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
 ITER_BYTES_UPDATE = 88           # SURVEY 8d's model, per pixel per sweep: read M 20 + R0 20 + R1 20, write M' 20 + flow 8
 ITER_BYTES_MOVED = 80            # what the kernel has to move: the flow of an updating sweep is consumed inside the kernel (store_flow = 0)
 ITER_BYTES_LAST = 28             # last sweep of a layer: read M 20, write flow 8
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 
 
 def b_alg_per_pair(layers, W, H, iters):
@@ -63,13 +80,25 @@ def source_hash(schedule=None):
 def usable_cores():
     """Host cores this process may actually run on: the affinity mask, capped by a cgroup CPU quota if there is one."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    q = _cgroup_cores()
+    return n if q is None else max(1, min(n, q))
+
+
+def pin_rank_to_its_cores(local_rank: int, local_world: int):
+    """N ranks share the node's host cores (and, on this pool, one cgroup quota of 16 cores): each rank's threads -- the enqueueing
+    thread, the staging threads, the runtime's helpers -- are confined to a core set of its own, usable cores // ranks wide, BEFORE
+    anything touches the GPU (threads started later inherit the mask).  Returns the number of cores this rank got; a single rank
+    keeps every usable core (its CPU-baseline leg wants them)."""
+    if local_world <= 1 or not hasattr(os, "sched_setaffinity"):
+        return usable_cores()
+    cores = sorted(os.sched_getaffinity(0))
+    per = max(1, min(len(cores), usable_cores()) // local_world)
+    mine = cores[local_rank * per:(local_rank + 1) * per] or cores[-per:]
     try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
-    except (OSError, ValueError):
-        pass
-    return n
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return usable_cores()
+    return len(mine)
 
 
 def cpu_flow_fn():
@@ -212,6 +241,22 @@ def traffic_record(want):
     return None, ("no committed PMC record matches this build / shape (" + "; ".join(why) + "): null" if why else "no PMC record committed: null")
 
 
+def trace_record(W, H, B, levels):
+    """The same union from the committed rocprofv3 kernel trace of this configuration (profiles/<round>/sweep_busy_*.txt, written by
+    tools/profile_round.sh on a traced run of the headline loop): (GB/s on the union, traced ms per step) or (None, None).  A traced
+    step is slower than an untraced one -- the tracer's cost per dispatch falls on ~1 600 launches per step -- so this figure is the
+    lower of the two; the bench line carries both."""
+    import re
+    name = {(1920, 1080, 64, 1): "1080p_b64", (3840, 2160, 16, 5): "4k_l5_b16", (1280, 720, 1, 1): "720p_b1"}.get((W, H, B, levels))
+    path = os.path.join(ROOT, "profiles", PROFILE_ROUND, f"sweep_busy_{name}.txt") if name else None
+    if not path or not os.path.exists(path):
+        return None, None
+    txt = open(path).read()
+    m = re.search(r"([0-9.]+) GB/s on the union", txt)
+    t = re.search(r"traced step\s+([0-9.]+) ms", txt)
+    return (float(m.group(1)) if m else None), (float(t.group(1)) if t else None)
+
+
 def sweep_roofline(ctx, run_batch, B, layers, W, H, levels, schedule, step_ms, ceil=None):
     """Roofline of the dominant kernel (the sweeps) for the workload run_batch() enqueues, measured live with HIP events in two extra
     passes outside any timed region: (1) events around every launch -> per-class sums, launch counts, avg launch duration (what
@@ -246,8 +291,11 @@ def sweep_roofline(ctx, run_batch, B, layers, W, H, levels, schedule, step_ms, c
     # measured on.  Per launch, like `achieved`.  null unless the record matches this build, shape, batch and schedule.
     traffic, traffic_source = traffic_record({"source_hash": source_hash(schedule), "width": W, "height": H, "batch": B, "levels": levels,
                                               "launches": launches})
+    from_trace, traced_step_ms = trace_record(W, H, B, levels)
     return {"bound": "hbm", "served_by": "infinity_cache", "kernel": "k_blur_iter_fast (all sweep launches of a step)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "achieved_from_trace": from_trace, "frac_from_trace": None if from_trace is None else round(from_trace / HBM_PEAK_GBS, 4),
+            "traced_step_ms": traced_step_ms, "untraced_step_ms": round(step_ms, 3),
             "achieved_is": "effective algorithmic bandwidth = bytes the sweeps have to move (80 B/px per updating sweep: M, R0, R1 in, M' out -- "
                            "the flow of all but a layer's last sweep never leaves the kernel; 28 B/px for the last) / time during which at least one "
                            "sweep launch runs.  The schedule keeps every pair's band of M / R0 / R1 inside the 256 MB Infinity Cache between "
@@ -331,6 +379,12 @@ def run_config_leg(name, W, H, B, levels, calls, pairs_to_check, verify=True, ce
     out["roofline"] = sweep_roofline(ctx, call, B, layers, W, H, levels, out["schedule"], ev_ms / calls, ceil)
     out["host_enqueue_share_of_call"] = round(out["host_enqueue_ms_per_call"] / (ev_ms / calls), 3)
     if B == 1:
+        # BASELINE config 2 is a per-frame detector: the distribution of ONE call's latency (enqueue + wait), 1 200 calls
+        lat = []
+        for _ in range(1200):
+            t0 = time.perf_counter(); call(); ctx.sync(); lat.append(1e3 * (time.perf_counter() - t0))
+        lat = np.sort(np.asarray(lat))
+        out["latency_calls"], out["median_ms"], out["p99_ms"], out["max_ms"] = len(lat), round(float(np.median(lat)), 4), round(float(lat[int(0.99 * len(lat))]), 4), round(float(lat[-1]), 4)
         out["lanes"] = lanes_leg(ctx, W, H, levels, (d_prev, d_next, d_smp), calls, balg)
         if not out["lanes"]["records_identical_across_contexts"]:
             out["failed_pairs"] = out.get("failed_pairs", []) + [-1]
@@ -647,6 +701,68 @@ class RecordExchange:
             self.dist.destroy_process_group()
 
 
+ROOFLINE_KEYS = ("bound", "served_by", "achieved", "peak", "unit", "frac", "achieved_from_trace", "frac_from_trace", "traced_step_ms", "untraced_step_ms",
+                 "traffic", "alg_bytes_per_launch_avg", "avg_launch_ms", "launches_per_step", "kernel_busy_ms", "launches_in_flight",
+                 "frac_of_measured_ceiling", "kernel_share_of_step", "device_busy_ms")
+
+
+def compact_line(full, detail_path):
+    """The bench line: numbers, no prose (the driver keeps the TAIL of a line -- the headline's own numbers, the
+    roofline, the CPU baseline and the API loops come before the per-configuration legs).  Every key is explained once, in DESIGN.md
+    section 6; the verbose record of this run is the --detail file."""
+    def pick(d, keys):
+        return {k: d[k] for k in keys if k in d}
+
+    def roof(r):
+        out = pick(r, ROOFLINE_KEYS)
+        out["kernel"] = "k_blur_iter_fast"
+        c = r.get("measured_ceiling") or {}
+        out["ceiling_GBs"] = {"infinity_cache": c.get("infinity_cache_GBs"), "hbm": c.get("hbm_GBs")}
+        return out
+
+    line = pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"))
+    cfg = full["config"]
+    line["config"] = {"workload": f"{cfg['workload'].split(',')[0]}, batch {cfg['global_batch'] // full['n_gpus']} per GPU, Farneback + FoE + phi/threshold + box",
+                      "global_batch": cfg["global_batch"], "parallelism": cfg["parallelism"], "comm_ranks": cfg["comm_ranks"],
+                      "record_exchange": cfg["record_exchange"], "torch_in_process": cfg["torch_in_process"],
+                      "host_cores_per_rank": cfg["host_cores_per_rank"], "runtime": cfg["runtime"]}
+    line.update(pick(full, ("hip_event_ms_per_step", "device_busy_ms", "pipeline_alg_bytes_per_pair", "pipeline_frac_of_8TBs", "host_enqueue_ms_per_step",
+                            "host_enqueue_share_of_step", "value_incl_h2d", "value_incl_h2d_pipelined", "source_hash", "gathered_rank_blocks_distinct", "rehearsal")))
+    if "roofline" in full:
+        line["roofline"] = roof(full["roofline"])
+    if "cpu_baseline" in full:
+        cb = full["cpu_baseline"]
+        line["cpu_baseline"] = pick(cb, ("value", "unit", "cores", "kind"))
+        line["cpu_baseline"]["sample"] = cb["sample"].split(",")[0]
+        if "all_cores" in cb:
+            line["cpu_baseline"]["all_cores"] = pick(cb["all_cores"], ("value", "cores", "host_cores", "pairs", "seconds"))
+    if "api_loop" in full:
+        al = full["api_loop"]
+        line["api_loop"] = {k: ({kk: vv for kk, vv in v.items() if kk != "flow_seam"} if isinstance(v, dict) else v) for k, v in al.items() if k != "workload"}
+    if "video_sequence" in full:
+        line["video_sequence"] = pick(full["video_sequence"], ("value", "ms_per_step", "ms_per_step_as_two_batches"))
+    if "verification" in full:
+        v = full["verification"]
+        line["verified_pairs"] = full["verified_pairs"]
+        line["verification"] = {"failed_pairs": v["failed_pairs"], "all_pairs_equal_plain_schedule": v.get("all_pairs_equal_plain_schedule"),
+                                "flow_epe_px": pick(v["flow_epe_px"], ("mean", "p99.9", "max", "against"))}
+    if "configs" in full:
+        line["configs"] = {}
+        for name, c in full["configs"].items():
+            o = pick(c, ("ms_per_call_hip_events", "ms_per_call_wall", "ms_per_pair", "pairs_per_s", "frac", "median_ms", "p99_ms", "max_ms", "latency_calls",
+                         "host_enqueue_ms_per_call", "verified_pairs", "failed_pairs", "all_pairs_equal_plain_schedule"))
+            if "flow_epe_px" in c:
+                o["flow_epe_px"] = pick(c["flow_epe_px"], ("mean", "p99.9", "max"))
+            if "roofline" in c:
+                o["roofline"] = roof(c["roofline"])
+            if "lanes" in c:
+                o["lanes"] = {k: v for k, v in c["lanes"].items() if k != "is"}
+            line["configs"][name] = o
+    if detail_path:
+        line["detail"] = detail_path
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -673,6 +789,7 @@ def main():
     ap.add_argument("--simulate-socket-failure", action="store_true", help="(tests) the last rank reports that its communicator did not come up: every rank "
                     "must agree to fall back to the torch path")
     ap.add_argument("--no-api-loop", action="store_true", help="skip the reference-shaped loops leg (Processor.run_detection_batched / run_detection on host frames)")
+    ap.add_argument("--detail", default=None, help="where the verbose record of the run goes (default: gpurun_out/bench_detail.json when that directory exists)")
     ap.add_argument("--no-configs", action="store_true", help="skip the extra BASELINE configuration legs (C2: 1280x720 batch 1; C5 share: 3840x2160, 5 levels, batch 16)")
     args = ap.parse_args()
 
@@ -696,6 +813,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if args.rehearse_on_one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1 or os.environ.get("MAVFLOW_BENCH_DIST") == "1"
+    host_cores = pin_rank_to_its_cores(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     ex = RecordExchange(args, rank, world, local_rank) if distributed else None
     if ex is not None and ex.mode == "torch":
         ex.init_torch()                                # torch BEFORE libmavflow: the library then binds to the runtime torch loaded
@@ -886,53 +1004,59 @@ def main():
         pairs = world * B * args.steps
         value = pairs / elapsed
         balg = b_alg_per_pair(layers, W, H, ctx.fb.iterations)
-        out = {"metric": "frame-pairs/sec at 1920x1080" if (W, H) == (1920, 1080) else f"frame-pairs/sec at {W}x{H}",
-               "value": round(value, 2), "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": f"{W}x{H}, batch={B} frame pairs per GPU, Farneback(0.4,{ctx.fb.levels},12,10,8,1.2,0) "
-                                      f"+ FoE(1000 pairs) + phi/threshold + box, {len(layers)} pyramid layers",
-                          "global_batch": world * B, "parallelism": f"frame-parallel x{world}" + (", all-gather of 32-B records" if world > 1 else ""),
-                          "record_exchange": exchange, "comm_ranks": comm_ranks, "torch_in_process": "torch" in sys.modules,
-                          "schedule": schedule, "runtime": _lib.runtime_info()},
-               "hip_event_ms_per_step": round(ev_ms / args.steps, 3),
-               "pipeline_alg_bytes_per_pair": balg,
-               "pipeline_alg_GBs": round(value / world * balg / 1e9, 1),
-               "pipeline_frac_of_8TBs": round(value / world * balg / (HBM_PEAK_GBS * 1e9), 4),
-               "pipeline_frac_is": "whole-path algorithmic bytes per pair (SURVEY 8d) x pairs/s / 8 TB/s: an effective rate, partly served by the Infinity Cache",
-               "source_hash": source_hash(schedule), "kernel_source_hash": source_hash()}
-        out["host_enqueue_ms_per_step_in_loop"] = round(1e3 * enq_loop / args.steps, 3)
+        # `full`: everything this run measured, with the prose that says how (written to --detail, default gpurun_out/bench_detail.json);
+        # the ONE line on stdout carries the numbers only -- what each key means is in DESIGN.md section 6 and profiles/README.md
+        full = {"metric": "frame-pairs/sec at 1920x1080" if (W, H) == (1920, 1080) else f"frame-pairs/sec at {W}x{H}",
+                "value": round(value, 2), "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"{W}x{H}, batch={B} frame pairs per GPU, Farneback(0.4,{ctx.fb.levels},12,10,8,1.2,0) "
+                                       f"+ FoE(1000 pairs) + phi/threshold + box, {len(layers)} pyramid layers",
+                           "global_batch": world * B, "parallelism": f"frame-parallel x{world}" + (", all-gather of 32-B records" if world > 1 else ""),
+                           "record_exchange": exchange, "comm_ranks": comm_ranks, "torch_in_process": "torch" in sys.modules,
+                           "host_cores_per_rank": host_cores, "schedule": schedule, "runtime": _lib.runtime_info()},
+                "hip_event_ms_per_step": round(ev_ms / args.steps, 3),
+                "pipeline_alg_bytes_per_pair": balg,
+                "pipeline_alg_GBs": round(value / world * balg / 1e9, 1),
+                "pipeline_frac_of_8TBs": round(value / world * balg / (HBM_PEAK_GBS * 1e9), 4),
+                "source_hash": source_hash(schedule), "kernel_source_hash": source_hash()}
+        full["host_enqueue_ms_per_step_in_loop"] = round(1e3 * enq_loop / args.steps, 3)
         if enqueue_ms is not None:
-            out["host_enqueue_ms_per_step"] = round(enqueue_ms, 3)
-            out["host_enqueue_share_of_step"] = round(enqueue_ms / (1e3 * elapsed / args.steps), 3)
-            out["host_enqueue_is"] = ("wall time of one step's mav_process_batch_dev (+ all-gather) call issued into an idle queue, median of 7 "
-                                      "(the *_in_loop figure is the timed loop's enqueue time / steps and includes queue back-pressure); "
-                                      "roofline.kernel_launches_per_step_all_classes launches + the fork / join events per step")
+            full["host_enqueue_ms_per_step"] = round(enqueue_ms, 3)
+            full["host_enqueue_share_of_step"] = round(enqueue_ms / (1e3 * elapsed / args.steps), 3)
         if gathered_distinct is not None:
-            out["gathered_rank_blocks_distinct"] = gathered_distinct
+            full["gathered_rank_blocks_distinct"] = gathered_distinct
         if args.rehearse_on_one_gpu:
-            out["rehearsal"] = f"{world} ranks share ONE GPU, records exchanged on the host: a functional run of the N > 1 path, not a scaling measurement"
-        if world > 1:
-            out["scaling_note"] = "per-GPU work fixed (weak); efficiency is the driver's to compute from the per-N values"
+            full["rehearsal"] = f"{world} ranks share ONE GPU, records exchanged on the host: a functional run of the N > 1 path, not a scaling measurement"
         if h2d_ms:
-            out["value_incl_h2d"] = round(B / (h2d_ms * 1e-3), 2)
-            out["value_incl_h2d_pipelined"] = round(B / (h2d_pipe_ms * 1e-3), 2)
-        if video:
-            out["video_sequence"] = video
+            full["value_incl_h2d"] = round(B / (h2d_ms * 1e-3), 2)
+            full["value_incl_h2d_pipelined"] = round(B / (h2d_pipe_ms * 1e-3), 2)
         if roofline:
-            out["roofline"] = roofline
-        if api_loop:
-            out["api_loop"] = api_loop
-            failed = failed or not api_loop["batched_and_unbatched_results_identical"]
-        if configs:
-            out["configs"] = configs
-            failed = failed or any(c.get("failed_pairs") for c in configs.values())
-        if verification:
-            out.update({"verified_pairs": verification["verified_pairs"], "verification": {k: v for k, v in verification.items() if k != "verified_pairs"}})
-            failed = failed or bool(verification["failed_pairs"])
+            full["device_busy_ms"] = roofline["device_busy_ms"]
+            full["roofline"] = roofline
         if world == 1 and args.cpu_pairs > 0:
-            out["cpu_baseline"] = cpu_baseline(prev, nxt, samples, min(args.cpu_pairs, B), args.levels)
-        print(json.dumps(out), flush=True)
+            full["cpu_baseline"] = cpu_baseline(prev, nxt, samples, min(args.cpu_pairs, B), args.levels)
+        if api_loop:
+            full["api_loop"] = api_loop
+            failed = failed or not api_loop["batched_and_unbatched_results_identical"]
+        if video:
+            full["video_sequence"] = video
+        if verification:
+            full.update({"verified_pairs": verification["verified_pairs"], "verification": {k: v for k, v in verification.items() if k != "verified_pairs"}})
+            failed = failed or bool(verification["failed_pairs"])
+        if configs:
+            full["configs"] = configs
+            failed = failed or any(c.get("failed_pairs") for c in configs.values())
+        detail = args.detail
+        if detail is None and os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+            detail = os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+        if detail:
+            try:
+                with open(detail, "w") as f:
+                    json.dump(full, f, indent=1)
+            except OSError:
+                detail = None
+        print(json.dumps(compact_line(full, os.path.relpath(detail, ROOT) if detail else None)), flush=True)
     ctx.close()
     if failed:
         sys.exit(3)

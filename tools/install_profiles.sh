@@ -12,6 +12,7 @@ cp "$R/pmc_summary_pmc720.txt" "$P/pmc_summary_720p_b1.txt"
 cp "$R/traffic.json" "$R/traffic_4k.json" "$R/traffic_720p.json" "$P/"
 cp "$R/sweep_busy_kt1080.txt" "$P/sweep_busy_1080p_b64.txt"
 cp "$R/sweep_busy_kt4k.txt" "$P/sweep_busy_4k_l5_b16.txt"
+cp "$R/sweep_busy_kt720.txt" "$P/sweep_busy_720p_b1.txt"
 cp "$R/step_anatomy_kt1080.txt" "$P/step_anatomy_1080p_b64.txt"
 cp "$R/step_anatomy_kt4k.txt" "$P/step_anatomy_4k_l5_b16.txt"
 cp "$R"/untraced_anatomy_*.txt "$R"/layer_image_launches_*.txt "$P/"
@@ -24,5 +25,5 @@ round=$(basename "$P")
 sed -i "s#\"source\": \"[^ ]*/pmc1080/summary.txt#\"source\": \"profiles/$round/pmc_summary_1080p_b64.txt#" "$P/traffic.json"
 sed -i "s#\"source\": \"[^ ]*/pmc4k/summary.txt#\"source\": \"profiles/$round/pmc_summary_4k_l5_b16.txt#" "$P/traffic_4k.json"
 sed -i "s#\"source\": \"[^ ]*/pmc720/summary.txt#\"source\": \"profiles/$round/pmc_summary_720p_b1.txt#" "$P/traffic_720p.json"
-sed -i "s#^[^ ]*/kt1080/runc/#(box) kt1080/runc/#; s#^[^ ]*/kt4k/runc/#(box) kt4k/runc/#" "$P"/sweep_busy_*.txt
+sed -i "s#^[^ ]*/kt1080/runc/#(box) kt1080/runc/#; s#^[^ ]*/kt4k/runc/#(box) kt4k/runc/#; s#^[^ ]*/kt720/runc/#(box) kt720/runc/#" "$P"/sweep_busy_*.txt
 ls "$P" | wc -l

@@ -12,6 +12,7 @@ CLEAN="--cpu-pairs 0 --no-configs --no-verify --no-profile --no-api-loop"
 # untraced records first: the algorithmic bytes per sweep launch (roofline block) the unions below are quoted on
 timeout -k 10 300 python3 bench.py --steps 10 --warmup 3 --cpu-pairs 0 --no-configs --no-api-loop > "$out/untraced1080.json" 2> "$out/untraced1080.err" || exit 1
 timeout -k 10 300 python3 bench.py --steps 10 --warmup 3 --cpu-pairs 0 --no-configs --no-api-loop $B4K > "$out/untraced4k.json" 2> "$out/untraced4k.err" || exit 1
+timeout -k 10 300 python3 bench.py --steps 200 --warmup 20 --cpu-pairs 0 --no-configs --no-api-loop --width 1280 --height 720 --batch 1 > "$out/untraced720.json" 2> "$out/untraced720.err" || exit 1
 # 5 + 2 steps each: the stats table then holds 7 identical steps and nothing else
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt1080" -- python3 bench.py --steps 5 --warmup 2 $CLEAN > "$out/kt1080.json" 2> "$out/kt1080.err" || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt4k" -- python3 bench.py --steps 5 --warmup 2 $CLEAN $B4K > "$out/kt4k.json" 2> "$out/kt4k.err" || exit 1
@@ -24,11 +25,13 @@ python3 tools/make_traffic.py "$out/pmc1080" "$out/traffic.json" --batch 64 > /d
 python3 tools/make_traffic.py "$out/pmc4k" "$out/traffic_4k.json" --width 3840 --height 2160 --levels 5 --batch 16 > /dev/null || exit 1
 python3 tools/make_traffic.py "$out/pmc720" "$out/traffic_720p.json" --width 1280 --height 720 --levels 1 --batch 1 > /dev/null || exit 1
 # sweep launches overlap (two pairs in flight): busy time = union of the dispatch intervals of the kernel trace
-for t in kt1080 kt4k; do
+for t in kt1080 kt4k kt720; do
   u=${t/kt/untraced}
   per=$(python3 -c "import json,sys; print(json.loads([l for l in open('$out/$u.json') if l.startswith('{')][-1])['roofline']['alg_bytes_per_launch_avg'])")
   python3 tools/trace_union.py "$out"/$t/runc/*_kernel_trace.csv --bytes-per-dispatch "$per" > "$out/sweep_busy_$t.txt" || exit 1
-  python3 tools/step_anatomy.py "$out"/$t/runc/*_kernel_trace.csv 3 > "$out/step_anatomy_$t.txt" || exit 1
+  # the step time of the TRACED run itself (its own bench line) and of the untraced one: bench.py quotes both next to the two rates
+  python3 -c "import json; t=json.loads([l for l in open('$out/$t.json') if l.startswith('{')][-1]); u=json.loads([l for l in open('$out/$u.json') if l.startswith('{')][-1]); print(f\"  traced step  {t['ms_per_step']:.3f} ms per step ({t['steps']} timed steps under rocprofv3 --kernel-trace); untraced {u['ms_per_step']:.3f} ms\")" >> "$out/sweep_busy_$t.txt" || exit 1
+  [ "$t" = kt720 ] || python3 tools/step_anatomy.py "$out"/$t/runc/*_kernel_trace.csv 3 > "$out/step_anatomy_$t.txt" || exit 1
 done
 python3 tools/trace_timeline.py "$out"/ktc2/runc/*_kernel_trace.csv --last 27 > "$out/c2_timeline.txt" || exit 1
 # the same anatomy WITHOUT a tracer (HIP events around runs of launches / around every launch) and the layer-image kernels per launch
