@@ -747,8 +747,10 @@ def _one_stream_per_lane(ctxs) -> None:
     per frame when the runtime happened to spread the six streams well, 0.61 (= one lane) after an earlier context had shifted the
     assignment, 0.79 with an eight-queue pool; one stream per lane makes it 0.47 - 0.48 in every order (profiles/r05/lanes_probe.txt).
     A single lane keeps its copy stream: there the upload of frame i + 1 overlaps the chain of frame i."""
+    want = 1 if len(ctxs) > 1 else 0
     for c in ctxs:
-        c.set_option("inline_uploads", 1 if len(ctxs) > 1 else 0)
+        if c.get_option("inline_uploads") != want:        # (setting it drains the context's streams: not on a context that has it already)
+            c.set_option("inline_uploads", want)
 
 
 class LanedFlowStage:

@@ -191,6 +191,11 @@ class Processor:
         if pipe is None or any(a is not b or not b.alive for a, b in zip(pipe.ctxs, ctxs)):
             if pipe is not None:
                 pipe.close()
+            # a seam that shows its lanes one by one (_flow_ctxs' fallback) makes this grow [c0] -> [c0, c1] -> ...: the pipelines over
+            # the smaller sets would keep their three slots of device and page-locked buffers on the same contexts until release()
+            mine = set(key[0])
+            for k in [k for k in self._pipes if k[1] == batch and k != key and set(k[0]) < mine]:
+                self._pipes.pop(k).close()
             pipe = pipeline.LanedPipeline(ctxs, batch)
             pipe.set_params(foe_params=self.focus_of_expansion._foe_params(1000))
             self._pipes[key] = pipe

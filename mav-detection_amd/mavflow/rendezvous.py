@@ -14,11 +14,15 @@ wins).  torch.distributed stays available as the fallback path of bench.py.
                       a file named after MASTER_PORT and the launcher's pid (every worker's parent), which the other ranks poll.
 
 Protocol: one request per line, `SET key hex`, `GET key timeout_s`, `ADD key n`; one reply per line (`OK`, the hex value, the new
-count, or `TIMEOUT`).  Values are hex strings: no framing, no pickling, nothing executable crosses the socket.
+count, or `TIMEOUT`).  Values are hex strings: no framing, no pickling, nothing executable crosses the socket.  The first line of every
+connection is `AUTH token`: the store draws a random token when it starts and hands it to the ranks with its address (the launcher's
+environment, or the 0600 port file), so that another user's process on the node can neither publish a forged ncclUniqueId or elapsed
+time nor flip the "communicator came up" flags; a connection that does not present it is closed.
 """
 from __future__ import annotations
 
 import os
+import secrets
 import socket
 import socketserver
 import tempfile
@@ -33,9 +37,15 @@ class Store:
     def __init__(self, host: str = "127.0.0.1", port: int = 0):
         data: Dict[str, str] = {}
         cond = threading.Condition()
+        token = self.token = secrets.token_hex(16)
 
         class Handler(socketserver.StreamRequestHandler):
             def handle(self):
+                first = self.rfile.readline().decode("ascii", "replace").split()
+                if len(first) != 2 or first[0] != "AUTH" or not secrets.compare_digest(first[1], token):
+                    return                                # not one of ours: no reply, connection closed
+                self.wfile.write(b"OK\n")
+                self.wfile.flush()
                 for raw in self.rfile:
                     parts = raw.decode("ascii", "replace").split()
                     if not parts:
@@ -78,6 +88,11 @@ class Store:
         self._thread.start()
         return self.host, self.port
 
+    @property
+    def address(self) -> str:
+        """host:port:token -- what a rank needs to join (MAVFLOW_RDZV, the port file)"""
+        return f"{self.host}:{self.port}:{self.token}"
+
     def stop(self):
         self._server.shutdown()
         self._server.server_close()
@@ -88,8 +103,9 @@ class RendezvousError(RuntimeError):
 
 
 class Client:
-    def __init__(self, host: str, port: int, rank: int, world: int, timeout: float = 120.0, store: Optional[Store] = None):
+    def __init__(self, host: str, port: int, rank: int, world: int, timeout: float = 120.0, store: Optional[Store] = None, token: str = ""):
         self.rank, self.world, self.timeout = int(rank), int(world), float(timeout)
+        self._broken = False
         self._store = store                               # kept alive (and stopped) by the rank that hosts it
         deadline = time.monotonic() + self.timeout
         while True:
@@ -103,11 +119,23 @@ class Client:
         self._sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
         self._file = self._sock.makefile("rwb")
         self._epoch = 0
+        if self._ask(f"AUTH {token or (store.token if store is not None else '-')}") != "OK":
+            raise RendezvousError(f"rank {rank}: the rendezvous store refused the token")
 
-    def _ask(self, line: str) -> str:
-        self._file.write((line + "\n").encode("ascii"))
-        self._file.flush()
-        reply = self._file.readline()
+    def _ask(self, line: str, wait: Optional[float] = None) -> str:
+        """One request, one reply.  `wait`: how long the STORE may hold the reply back (a blocking GET); the socket gives it that long
+        plus a margin, whatever the connection's own timeout is.  A reply that does not come leaves request and reply out of step:
+        the client is unusable from then on and says so."""
+        if self._broken:
+            raise RendezvousError(f"rank {self.rank}: the rendezvous connection is out of step after a timeout")
+        try:
+            self._sock.settimeout((self.timeout if wait is None else max(wait, 0.0)) + 10.0)
+            self._file.write((line + "\n").encode("ascii"))
+            self._file.flush()
+            reply = self._file.readline()
+        except (socket.timeout, TimeoutError):
+            self._broken = True
+            raise RendezvousError(f"rank {self.rank}: no reply from the rendezvous store to '{line.split()[0]} {line.split()[1] if ' ' in line else ''}'")
         if not reply:
             raise RendezvousError(f"rank {self.rank}: the rendezvous store closed the connection")
         return reply.decode("ascii").strip()
@@ -117,7 +145,8 @@ class Client:
             raise RendezvousError(f"rank {self.rank}: SET {key} refused")
 
     def get(self, key: str, timeout: Optional[float] = None) -> bytes:
-        r = self._ask(f"GET {key} {self.timeout if timeout is None else timeout}")
+        t = self.timeout if timeout is None else float(timeout)
+        r = self._ask(f"GET {key} {t}", wait=t)
         if r == "TIMEOUT":
             raise RendezvousError(f"rank {self.rank}: timed out waiting for '{key}'")
         return b"" if r == "-" else bytes.fromhex(r)
@@ -177,8 +206,8 @@ def from_env(timeout: float = 120.0) -> Client:
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     where = os.environ.get("MAVFLOW_RDZV")
     if where:
-        host, port = where.rsplit(":", 1)
-        return Client(host, int(port), rank, world, timeout)
+        host, port, token = (where.split(":") + [""])[:3]
+        return Client(host, int(port), rank, world, timeout, token=token)
     path = _port_file(os.environ.get("MASTER_PORT", "0"))
     if rank == 0:
         store = Store()
@@ -190,7 +219,7 @@ def from_env(timeout: float = 120.0) -> Client:
             pass
         fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)   # ours, fresh, no symlink followed
         with os.fdopen(fd, "w") as f:
-            f.write(f"{host}:{port}")
+            f.write(store.address)
         os.replace(tmp, path)                             # atomic: a reader never sees a half-written file
         c = Client(host, port, rank, world, timeout, store=store)
         try:
@@ -207,7 +236,7 @@ def from_env(timeout: float = 120.0) -> Client:
             if os.lstat(path).st_uid != os.getuid():      # the temporary directory is shared: only a file of our own is believed
                 raise OSError("rendezvous port file is not ours")
             with open(path) as f:
-                host, port = f.read().strip().rsplit(":", 1)
+                host, port, token = f.read().strip().split(":")
             if host != "127.0.0.1":
                 raise ValueError("rendezvous store must be on localhost")
             break
@@ -215,7 +244,7 @@ def from_env(timeout: float = 120.0) -> Client:
             if time.monotonic() > deadline:
                 raise RendezvousError(f"rank {rank}: rank 0 never published the rendezvous port ({path})")
             time.sleep(0.02)
-    c = Client(host, int(port), rank, world, timeout)
+    c = Client(host, int(port), rank, world, timeout, token=token)
     c.barrier("connected", timeout)
     return c
 
@@ -232,7 +261,7 @@ def spawn_ranks(argv: List[str], n: int, env: Optional[dict] = None) -> int:
     procs = []
     try:
         for r in range(n):
-            e = dict(os.environ if env is None else env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MAVFLOW_RDZV=f"{host}:{port}",
+            e = dict(os.environ if env is None else env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MAVFLOW_RDZV=store.address,
                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(master_port),
                      HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
             procs.append(subprocess.Popen(argv, env=e))

@@ -467,6 +467,8 @@ def test_a_seam_that_hides_its_lanes_is_followed_anyway(mav):
         res[loop] = getattr(p, loop)()
         if loop == "run_detection":
             assert len(p._lane_seen) == 2
+            # the pipeline over the first lane alone went when the one over both lanes was built
+            assert len(p._pipes) == 1 and len(next(iter(p._pipes.values())).ctxs) == 2
         p.release()
     for i in range(N - 1):
         assert vars(res["run_detection"][i]) == vars(res["run_detection_staged"][i]), i

@@ -107,7 +107,7 @@ def test_store_values_are_plain_hex_and_a_missing_store_times_out():
     from mavflow import rendezvous
     store = rendezvous.Store()
     host, port = store.start()
-    c = rendezvous.Client(host, port, 0, 1, timeout=5)
+    c = rendezvous.Client(host, port, 0, 1, timeout=5, token=store.token)
     c.set("k", b"\x00\xff\x10")
     assert c.get("k") == b"\x00\xff\x10"
     assert c._ask("ADD n 2") == "2" and c._ask("ADD n 3") == "5" and c._ask("BOGUS") == "ERR"
@@ -115,3 +115,67 @@ def test_store_values_are_plain_hex_and_a_missing_store_times_out():
     store.stop()
     with pytest.raises(rendezvous.RendezvousError):
         rendezvous.Client("127.0.0.1", port, 0, 1, timeout=0.3)
+
+
+def test_store_refuses_connections_without_its_token():
+    """the store accepted SET / ADD from any local process.  Every connection now opens with the store's random token
+    (handed to the ranks with the address: the launcher's environment or the 0600 port file); anything else is closed unanswered."""
+    import socket
+    from mavflow import rendezvous
+    store = rendezvous.Store()
+    host, port = store.start()
+    assert len(store.token) == 32 and store.address == f"{host}:{port}:{store.token}"
+    with pytest.raises(rendezvous.RendezvousError):
+        rendezvous.Client(host, port, 0, 1, timeout=2, token="0" * 32)
+    with socket.create_connection((host, port), timeout=2) as sk:             # a raw client that skips the handshake gets nothing done
+        sk.sendall(b"SET uid.1 deadbeef\n")
+        sk.settimeout(2)
+        assert sk.recv(16) == b""                                             # closed, no reply
+    ok = rendezvous.Client(host, port, 0, 1, timeout=2, token=store.token)
+    with pytest.raises(rendezvous.RendezvousError):
+        ok.get("uid.1", 0.2)                                                  # the forged value never landed
+    ok.close()
+    store.stop()
+
+
+def test_a_get_may_wait_longer_than_the_connection_timeout_and_a_lost_reply_breaks_the_client():
+    """the connection's 120 s socket timeout used to cut a 300 s GET short with a TimeoutError, leaving request and reply
+    out of step.  A request now gives the socket its own wait + a margin; a reply that still does not come raises RendezvousError and
+    the client refuses further use."""
+    import threading
+    import time
+    from mavflow import rendezvous
+    store = rendezvous.Store()
+    host, port = store.start()
+    a = rendezvous.Client(host, port, 0, 2, timeout=0.5, token=store.token)   # connection timeout 0.5 s ...
+    b = rendezvous.Client(host, port, 1, 2, timeout=0.5, token=store.token)
+    threading.Timer(1.5, lambda: b.set("late", b"\x07")).start()
+    t0 = time.monotonic()
+    assert a.get("late", timeout=5.0) == b"\x07"                              # ... and a GET that is answered after 1.5 s
+    assert 1.0 < time.monotonic() - t0 < 4.0
+    with pytest.raises(rendezvous.RendezvousError, match="timed out"):
+        a.get("never", timeout=0.2)                                           # the store's own TIMEOUT reply: client still in step
+    assert a.get("late") == b"\x07"
+    a.close(); b.close(); store.stop()
+    # a store that accepts the token and then falls silent: the reply never comes
+    import socket
+    srv = socket.socket(); srv.bind(("127.0.0.1", 0)); srv.listen(1)
+    conns = []
+
+    def mute():
+        cn, _ = srv.accept()
+        conns.append(cn)
+        cn.recv(200)
+        cn.sendall(b"OK\n")                                                    # the AUTH reply, nothing afterwards
+    th = threading.Thread(target=mute, daemon=True); th.start()
+    c = rendezvous.Client("127.0.0.1", srv.getsockname()[1], 0, 1, timeout=0.2, token="x")
+    c.timeout = -9.7                                                          # a request's wait + the 10 s margin = 0.3 s
+    t0 = time.monotonic()
+    with pytest.raises(rendezvous.RendezvousError, match="no reply"):
+        c._ask("SET k 00")
+    assert time.monotonic() - t0 < 2.0
+    with pytest.raises(rendezvous.RendezvousError, match="out of step"):
+        c.get("k", 0.1)
+    for cn in conns:
+        cn.close()
+    srv.close()
