@@ -8,8 +8,9 @@ from mavflow.run_config import RunConfig
 a = sys.argv[1:]
 W, H, F, REPS = (int(a[0]), int(a[1]), int(a[2]), int(a[3])) if len(a) >= 4 else (1920, 1080, 96, 4)
 N = F + 1
+LANES = tuple(int(v) for v in a[4].split(",")) if len(a) >= 5 else (1, 2, 3)
 procs = {}
-for lanes in (1, 2, 3):
+for lanes in LANES:
     ds = SyntheticDataset(W, H, N, use_farneback=True, distinct=8, dangle=(0.004, -0.002, 0.001), lanes=lanes)
     for i in range(8):
         ds._pair(i); ds.get_gt_of(i)
@@ -21,7 +22,7 @@ for lanes in (1, 2, 3):
     procs[lanes] = (p, ds)
 for rep in range(REPS):
     row = []
-    for lanes in (1, 2, 3):
+    for lanes in LANES:
         p, ds = procs[lanes]
         p.frame_index = 0; p.detection_results = {}; p.config.results = {}
         np.random.seed(7)
