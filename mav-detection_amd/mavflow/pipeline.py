@@ -731,12 +731,14 @@ def auto_lanes(W: int, H: int, batch: int = 1, uploads: bool = True) -> int:
     """Contexts a stream of `batch`-pair calls at this frame size is spread over.  Device-resident inputs (uploads=False): 3 up to
     100 MB of finest-layer sweep working set per call (80 B per pixel and pair), 2 up to 200 MB (one 1080p pair: 166 MB), 1 beyond.
     With the frames crossing PCIe inside every call (the reference-shaped loops: a lane's upload sits on its one stream, in front of
-    its chain) one more lane fills those gaps: 4 up to 100 MB (the runtime's pool of hardware queues holds four; a fifth lane shares
-    one and loses), 3 up to 200 MB.  One-frame loop, ms per frame with 2 / 3 / 4 / 5 lanes: 1280x720 0.27 / 0.218 / 0.195 - 0.207 / 0.239,
-    1920x1080 0.47 / 0.44 - 0.46 / 0.474 (profiles/r06/api_loop_host_split.txt, lanes_api_probe.txt)."""
+    its chain) a third lane fills those gaps up to 200 MB as well: one-frame loop at 1080p 0.47 ms per frame with two lanes, 0.44 - 0.46
+    with three.  FOUR lanes at 1280x720 run at 0.195 - 0.207 ms per frame in a fresh process (three: 0.218) but at 0.266 inside bench.py,
+    after other contexts have come and gone: four lanes need every one of the runtime's four hardware queues to themselves, and any
+    other stream of the process takes one away.  Three is what holds in every order (profiles/r06/api_loop_host_split.txt,
+    lanes_api_probe.txt, final_bench.json)."""
     ws = 80 * W * H * batch
     if uploads:
-        return 4 if ws <= (100 << 20) else (3 if ws <= (200 << 20) else 1)
+        return 3 if ws <= (200 << 20) else 1
     return 3 if ws <= (100 << 20) else (2 if ws <= (200 << 20) else 1)
 
 
