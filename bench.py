@@ -436,7 +436,7 @@ def lanes_leg(ctx0, W, H, levels, inputs, calls, balg):
     return out
 
 
-def api_loop_leg(W=1920, H=1080, batch=64, n_batches=12, n_unbatched=96, staged=False, only_batched=False):
+def api_loop_leg(W=1920, H=1080, batch=64, n_batches=12, n_unbatched=288, staged=False, only_batched=False):
     """The door north_star says users come through: the reference-shaped loops of mavflow.processor on a pre-generated synthetic
     dataset -- host numpy frames in (pageable, one array per frame, as Dataset hands them out), filled FrameResults out.  Never
     `value`.  Each loop runs once to warm its context (workspace allocation, first launches) and is timed on its second run over the

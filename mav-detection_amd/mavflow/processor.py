@@ -177,6 +177,7 @@ class Processor:
         self.results_path = results_path if results_path is not None else getattr(self.dataset, "results_path", None)
         self._ctxs = []                                 # this loop's own contexts (never the helpers' shared, evictable ones)
         self._pipes = {}
+        self._stale_pipes = []                           # pipelines over a subset of the lanes now in use, until their last frames are collected
         self._seg_val = None
         self._center = None
 
@@ -193,9 +194,10 @@ class Processor:
                 pipe.close()
             # a seam that shows its lanes one by one (_flow_ctxs' fallback) makes this grow [c0] -> [c0, c1] -> ...: the pipelines over
             # the smaller sets would keep their three slots of device and page-locked buffers on the same contexts until release()
+            # (closed by _drop_stale_pipes once the loop has collected what it still has in flight on them)
             mine = set(key[0])
             for k in [k for k in self._pipes if k[1] == batch and k != key and set(k[0]) < mine]:
-                self._pipes.pop(k).close()
+                self._stale_pipes.append(self._pipes.pop(k))
             pipe = pipeline.LanedPipeline(ctxs, batch)
             pipe.set_params(foe_params=self.focus_of_expansion._foe_params(1000))
             self._pipes[key] = pipe
@@ -226,7 +228,13 @@ class Processor:
             self._lane_seen.append(flow.ctx)
         return list(self._lane_seen)
 
+    def _drop_stale_pipes(self) -> None:
+        for pipe in self._stale_pipes:
+            pipe.close()
+        self._stale_pipes = []
+
     def _close_pipes(self) -> None:
+        self._drop_stale_pipes()
         for pipe in self._pipes.values():
             pipe.close()
         self._pipes = {}
@@ -360,6 +368,7 @@ class Processor:
             now = self._pipeline(ctxs, 1)
             if now is not pipe:                                         # the flow moved to other contexts: drain the old pipeline first
                 finish(0)
+                self._drop_stale_pipes()
                 pipe = now
             kw, skies = self._sky_and_gt([i])
             self.sky_mask = skies[0]
