@@ -290,6 +290,7 @@ struct mav_ctx {
     struct Worker* worker = nullptr;     // mav_frame_step_post: the thread that enqueues posted steps (created by the first post)
     int upload_threads = 4;              // option "upload_threads"
     bool inline_uploads = false;         // option "inline_uploads": uploads go on the compute stream (no copy stream, no cross-stream events)
+    int stream_priority = 0;             // option "stream_priority": the compute stream's priority class (the runtime keeps a queue pool per class)
     const float* last_flow = nullptr;    // where the latest farneback / process_batch call wrote its flow (mav_last_flow_dev)
     const uint8_t *last_mf = nullptr, *last_md = nullptr;   // masks of the latest host-pointer detection call, still in their
     int last_mask_batch = 0;                                // staging blocks (mav_last_masks_tpr_fpr)
@@ -692,6 +693,7 @@ extern "C" int mav_get_option(mav_ctx* c, const char* name, long* value)
     if (!c || !name || !value) return fail(MAV_ERR_ARG, "mav_get_option: NULL argument");
     if (!strcmp(name, "upload_threads")) { *value = c->upload_threads; return MAV_OK; }
     if (!strcmp(name, "inline_uploads")) { *value = c->inline_uploads; return MAV_OK; }
+    if (!strcmp(name, "stream_priority")) { *value = c->stream_priority; return MAV_OK; }
     long tmp;
     if (!option_slot(c, name, &tmp)) return fail(MAV_ERR_ARG, "unknown option '%s'", name);
     *value = tmp;
@@ -706,6 +708,26 @@ extern "C" int mav_set_option(mav_ctx* c, const char* name, long value)
         if (c->copy_stream) HIPCHK(hipStreamSynchronize(c->copy_stream));      // nothing of the old mode is left in flight
         HIPCHK(hipStreamSynchronize(c->stream));
         c->inline_uploads = value != 0;
+        return MAV_OK;
+    }
+    if (!strcmp(name, "stream_priority")) {     // not part of the launch schedule
+        // The HIP runtime maps streams onto a pool of (by default four) hardware queues PER PRIORITY CLASS, least-used first; which
+        // queue a new stream gets depends on every stream the process has ever made.  Lanes -- contexts that take a stream of small calls
+        // in turn and must not share a queue (pipeline.py) -- ask for a class of their own: -1 = high.  The context's compute stream is
+        // re-created in that class; nothing may be in flight (the call drains it).
+        int lo = 0, hi = 0;
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));            // lo = least (numerically largest), hi = greatest
+        if (value < hi || value > lo) return fail(MAV_ERR_ARG, "option 'stream_priority' must be in [%d, %d], got %ld", hi, lo, value);
+        if ((int)value == c->stream_priority) return MAV_OK;
+        CHK(mav_worker_drain(c));
+        CHK(sync_all_streams(c));
+        if (c->copy_stream) HIPCHK(hipStreamSynchronize(c->copy_stream));
+        hipStream_t fresh = nullptr;
+        HIPCHK(hipStreamCreateWithPriority(&fresh, hipStreamNonBlocking, (int)value));
+        HIPCHK(hipStreamDestroy(c->stream));
+        c->stream = fresh;
+        c->stream_priority = (int)value;
         return MAV_OK;
     }
     if (!strcmp(name, "upload_threads")) {      // host side of mav_upload_gather; not part of the launch schedule (mav_schedule_info)

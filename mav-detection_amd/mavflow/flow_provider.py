@@ -45,7 +45,7 @@ class FarnebackFlowProvider:
                  lanes: Optional[int] = None) -> None:
         """on_device (window = 1): get_flow_uv returns a pipeline.DeviceArray -- the field stays on the GPU until somebody reads it,
         which Processor.run_detection never does (BGR frames are converted there too); off by default: a host float32 array.
-        lanes: contexts the on-device seam takes in turn (None: pipeline.auto_lanes -- 3 up to 1080p, 1 beyond)."""
+        lanes: contexts the on-device seam takes in turn (None: pipeline.auto_lanes -- 4 up to ~720p, 3 at 1080p, 1 beyond)."""
         from . import _lib
         self.get_gray, self.img_path, self.write_flo = get_gray, img_path, write_flo
         if window < 1 or (window > 1 and n_frames is None):

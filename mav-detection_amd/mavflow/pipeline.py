@@ -731,15 +731,17 @@ def auto_lanes(W: int, H: int, batch: int = 1, uploads: bool = True) -> int:
     """Contexts a stream of `batch`-pair calls at this frame size is spread over.  Device-resident inputs (uploads=False): 3 up to
     100 MB of finest-layer sweep working set per call (80 B per pixel and pair), 2 up to 200 MB (one 1080p pair: 166 MB), 1 beyond.
     With the frames crossing PCIe inside every call (the reference-shaped loops: a lane's upload sits on its one stream, in front of
-    its chain) a third lane fills those gaps up to 200 MB as well: one-frame loop at 1080p 0.47 ms per frame with two lanes, 0.44 - 0.46
-    with three.  FOUR lanes at 1280x720 run at 0.195 - 0.207 ms per frame in a fresh process (three: 0.218) but at 0.266 inside bench.py,
-    after other contexts have come and gone: four lanes need every one of the runtime's four hardware queues to themselves, and any
-    other stream of the process takes one away.  Three is what holds in every order (profiles/r06/api_loop_host_split.txt,
-    lanes_api_probe.txt, final_bench.json)."""
+    its chain) one more lane fills those gaps: 4 up to 100 MB, 3 up to 200 MB.  One-frame loop, ms per frame with 2 / 3 / 4 / 5 lanes:
+    1280x720 0.27 / 0.213 / 0.195 / 0.239, 1920x1080 0.477 / 0.443 / 0.47 (profiles/r06/lanes_api_probe.txt,
+    lane_queue_priority.txt).  Four lanes need all four hardware queues of their class -- which they have since the lanes' streams
+    live in a priority class of their own (_one_stream_per_lane); before that the fourth lane lost 20 % inside bench.py."""
     ws = 80 * W * H * batch
     if uploads:
-        return 3 if ws <= (200 << 20) else 1
+        return 4 if ws <= (100 << 20) else (3 if ws <= (200 << 20) else 1)
     return 3 if ws <= (100 << 20) else (2 if ws <= (200 << 20) else 1)
+
+
+LANE_STREAM_PRIORITY = -1     # high
 
 
 def _one_stream_per_lane(ctxs) -> None:
@@ -754,6 +756,13 @@ def _one_stream_per_lane(ctxs) -> None:
     for c in ctxs:
         if c.get_option("inline_uploads") != want:        # (setting it drains the context's streams: not on a context that has it already)
             c.set_option("inline_uploads", want)
+        # ... and the lanes' streams live in a priority class of their own (LANE_STREAM_PRIORITY): the runtime keeps a pool of hardware
+        # queues per class, so which queues the lanes get no longer depends on what other streams the process has made -- with ONE idle
+        # context created before the lanes the same three-lane loop ran at 0.31 instead of 0.215 ms per 720p frame
+        # (profiles/r06/lane_queue_priority.txt)
+        pr = LANE_STREAM_PRIORITY if len(ctxs) > 1 else 0
+        if c.get_option("stream_priority") != pr:
+            c.set_option("stream_priority", pr)
 
 
 class LanedFlowStage:

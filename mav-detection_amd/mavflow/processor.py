@@ -338,7 +338,7 @@ class Processor:
         total_mask are DeviceArray handles (read them and they are host arrays).  Frame 0 takes the reference's float32 path
         (detector.py:80-81).  The sample coordinates are drawn from np.random exactly where get_FOE_dense draws them.
         Software-pipelined: frame i's FrameResult is filled in (and its JSON written) after the following frames -- as many as the
-        pipeline has lanes (pipeline.auto_lanes: 3 contexts taken in turn for frames up to 1080p, whose one-pair chains of launches
+        pipeline has lanes (pipeline.auto_lanes: 3 - 4 contexts taken in turn for frames up to 1080p, whose one-pair chains of launches
         then interleave on the GPU) -- have been enqueued; results, files and their order are those of the plain loop."""
         from collections import deque
         pending = deque()

@@ -345,7 +345,7 @@ def test_lanes_give_the_single_context_results(mav):
     from collections import deque
     from mavflow import _lib
     from mavflow.pipeline import LanedFlowStage, LanedPipeline, auto_lanes
-    assert (auto_lanes(1280, 720), auto_lanes(1920, 1080), auto_lanes(3840, 2160), auto_lanes(1920, 1080, 64), auto_lanes(640, 480, 2)) == (3, 3, 1, 1, 3)
+    assert (auto_lanes(1280, 720), auto_lanes(1920, 1080), auto_lanes(3840, 2160), auto_lanes(1920, 1080, 64), auto_lanes(640, 480, 2)) == (4, 3, 1, 1, 4)
     assert (auto_lanes(1280, 720, uploads=False), auto_lanes(1920, 1080, uploads=False), auto_lanes(3840, 2160, uploads=False)) == (3, 2, 1)
     W, H, n = 320, 240, 7
     prev, nxt = synth.make_batch(W, H, n, distinct=n)
