@@ -359,7 +359,8 @@ typedef struct mav_frame_step {
 int mav_frame_step_dev(mav_ctx*, const mav_frame_step*);
 /* Post the step to the context's worker thread.  From the first post on until mav_worker_drain (or mav_destroy) the worker is the
  * thread that owns the context: the caller may post further steps and wait for tickets, and must call mav_worker_drain before any
- * other entry point of this context (the Python binding does so by itself).  *ticket identifies the step. */
+ * other entry point of this context (the Python binding does so by itself).  *ticket identifies the step.  mav_destroy lets the
+ * worker finish the step it is enqueueing and DROPS the ones still queued. */
 int mav_frame_step_post(mav_ctx*, const mav_frame_step*, uint64_t* ticket);
 /* Block until step `ticket` has been enqueued by the worker and, when `marker` is not NULL (the step's record_done), until that
  * marker has fired.  Returns the step's own return code (and sets mav_last_error to its message). */

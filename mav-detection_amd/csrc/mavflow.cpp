@@ -530,7 +530,7 @@ extern "C" int mav_destroy(mav_ctx* c)
 {
     if (!c) return MAV_OK;
     hipSetDevice(c->device);
-    stop_worker(c);                  // (enqueues what was posted, then leaves)
+    stop_worker(c);                  // (finishes the step it is enqueueing, drops the rest, leaves)
     (void)sync_all_streams(c);
     if (c->copy_stream) hipStreamSynchronize(c->copy_stream);
     if (c->stager) { c->stager->shutdown(); delete c->stager; c->stager = nullptr; }
@@ -1856,7 +1856,15 @@ static void worker_main(mav_ctx* c)
     std::unique_lock<std::mutex> lk(w->m);
     for (;;) {
         w->cv_job.wait(lk, [&] { return w->stop || !w->q.empty(); });
-        if (w->q.empty()) return;                              // stop, and nothing left to enqueue
+        if (w->stop) {
+            // mav_destroy: steps nobody waited for are DROPPED, not enqueued -- the host buffers they point to may be gone with
+            // whoever posted them; their tickets report MAV_ERR_STATE to a waiter that is still there
+            for (StepJob& j : w->q) w->failed[j.ticket] = {MAV_ERR_STATE, "the context was destroyed before this step was enqueued"};
+            if (!w->q.empty()) w->done = w->q.back().ticket;
+            w->q.clear();
+            w->cv_done.notify_all();
+            return;
+        }
         StepJob job = std::move(w->q.front());
         w->q.pop_front();
         lk.unlock();

@@ -402,7 +402,7 @@ class Context:
             for p in getattr(self, "_pinned", []):
                 self.lib.mav_host_free(self._h, p)
             self._pinned = []
-            self.lib.mav_destroy(self._h)            # (enqueues whatever was still posted, joins the worker)
+            self.lib.mav_destroy(self._h)            # (the worker finishes the step in hand, drops what is still queued, joins)
             self._h = None
             self._posted = False
 

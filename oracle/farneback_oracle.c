@@ -293,6 +293,14 @@ void fbo_polyexp(const float* src, int width, int height, int n, double sigma, f
     free(_row); free(kbuf);
 }
 
+/* Checker-side bookkeeping of the ONE discontinuity of the iteration: whether a pixel's displaced position (x + u, y + v) lies
+ * inside the second image (bilinear sample of R1) or not (the else-branch below).  A pixel whose decision changes from one update
+ * to the next sits on that discontinuity: an implementation that differs by one ulp may flip it one sweep earlier or later and is
+ * then a visible distance away for as long as the flip repeats (limit cycles along the image border, profiles/r06/border_cycle.txt).
+ * state / flips: one byte per pixel, NULL = not tracked; count_from: flips are counted in updates with index >= count_from. */
+typedef struct { uint8_t* state; uint8_t* flips; int update_index, count_from; } fbo_branch_track;
+static _Thread_local fbo_branch_track* g_track = 0;    /* set by calc_ex for the finest layer only (per calling thread) */
+
 /* FarnebackUpdateMatrices (A.5), rows [y0, y1) */
 void fbo_update_matrices_rows(const float* R0_, const float* R1, const float* flow_, int width, int height,
                               float* matM, int y0, int y1)
@@ -310,6 +318,15 @@ void fbo_update_matrices_rows(const float* R0_, const float* R1, const float* fl
             int x1 = cv_floor(fx), y1_ = cv_floor(fy);
             float r2, r3, r4, r5, r6;
             fx -= x1; fy -= y1_;
+            if (g_track) {
+                const uint8_t in = (unsigned)x1 < (unsigned)(width - 1) && (unsigned)y1_ < (unsigned)(height - 1);
+                uint8_t* st = g_track->state + (size_t)y * width + x;
+                if (g_track->update_index > 0 && g_track->update_index >= g_track->count_from && *st != in) {
+                    uint8_t* fl = g_track->flips + (size_t)y * width + x;
+                    if (*fl < 255) (*fl)++;
+                }
+                *st = in;
+            }
             if ((unsigned)x1 < (unsigned)(width - 1) && (unsigned)y1_ < (unsigned)(height - 1)) {
                 const float* ptr = R1 + (size_t)y1_ * step1 + (size_t)x1 * 5;
                 float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
@@ -462,7 +479,7 @@ void fbo_resize_flow(const float* prev, int pw, int ph, int w, int h, double mul
 /* FarnebackOpticalFlowImpl::calc, flags == 0 path. Returns 0 on success, <0 on bad arguments.
  * sys_last (nullable, H x W x 7 doubles): the finest layer's last sweep as fbo_blur_iter_sys reports it. */
 static int calc_ex(const uint8_t* prev, const uint8_t* next, int W, int H, const fbo_params* p, float* flow0, double* sys_last,
-                   int acc_float)
+                   int acc_float, uint8_t* flips_out)
 {
     if (!prev || !next || !flow0 || W <= 0 || H <= 0) return -1;
     if (!(p->pyr_scale > 0 && p->pyr_scale < 1) || p->levels < 0 || p->winsize < 2 || p->iterations < 0 ||
@@ -488,10 +505,22 @@ static int calc_ex(const uint8_t* prev, const uint8_t* next, int W, int H, const
         }
         free(I);
         float* M = (float*)malloc(sizeof(float) * (size_t)w * h * 5);
-        fbo_update_matrices(R[0], R[1], flow, w, h, M);
-        for (int i = 0; i < p->iterations; i++)
+        fbo_branch_track tr = {0, 0, 0, 0};
+        if (k == 0 && flips_out) {              /* finest layer: track the inside / outside decision over its updates; count the last four */
+            tr.state = (uint8_t*)calloc((size_t)w * h, 1);
+            tr.flips = flips_out;
+            memset(flips_out, 0, (size_t)w * h);
+            tr.count_from = p->iterations - 1 - 4 > 1 ? p->iterations - 1 - 4 : 1;
+            g_track = &tr;
+        }
+        fbo_update_matrices(R[0], R[1], flow, w, h, M);           /* update 0: from the up-sampled flow */
+        for (int i = 0; i < p->iterations; i++) {
+            tr.update_index = i + 1;                              /* update i + 1: from sweep i's flow (none after the last sweep) */
             fbo_blur_iter_ex(R[0], R[1], flow, M, w, h, p->winsize, i < p->iterations - 1,
                              (k == 0 && i == p->iterations - 1) ? sys_last : 0, acc_float);
+        }
+        g_track = 0;
+        free(tr.state);
         free(M); free(R[0]); free(R[1]);
         if (prevFlow) free(prevFlow);
         prevFlow = (k > 0) ? flow : 0;
@@ -502,16 +531,23 @@ static int calc_ex(const uint8_t* prev, const uint8_t* next, int W, int H, const
 
 int fbo_calc_sys(const uint8_t* prev, const uint8_t* next, int W, int H, const fbo_params* p, float* flow0, double* sys_last)
 {
-    return calc_ex(prev, next, W, H, p, flow0, sys_last, 0);
+    return calc_ex(prev, next, W, H, p, flow0, sys_last, 0, 0);
+}
+
+/* ... and flips (nullable, H x W bytes): per pixel, in how many of the finest layer's last four updates the inside / outside
+ * decision of its displaced position differed from the update before (fbo_branch_track). */
+int fbo_calc_track(const uint8_t* prev, const uint8_t* next, int W, int H, const fbo_params* p, float* flow0, double* sys_last, uint8_t* flips)
+{
+    return calc_ex(prev, next, W, H, p, flow0, sys_last, 0, flips);
 }
 
 int fbo_calc(const uint8_t* prev, const uint8_t* next, int W, int H, const fbo_params* p, float* flow0)
 {
-    return calc_ex(prev, next, W, H, p, flow0, 0, 0);
+    return calc_ex(prev, next, W, H, p, flow0, 0, 0, 0);
 }
 
 /* NOT OpenCV: calc() with float32 window sums (see fbo_blur_iter_ex); the sensitivity twin of oracle/tolerances.py. */
 int fbo_calc_f32sums(const uint8_t* prev, const uint8_t* next, int W, int H, const fbo_params* p, float* flow0)
 {
-    return calc_ex(prev, next, W, H, p, flow0, 0, 1);
+    return calc_ex(prev, next, W, H, p, flow0, 0, 1, 0);
 }

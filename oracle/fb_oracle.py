@@ -121,6 +121,32 @@ class Oracle:
             raise ValueError(f"fbo_calc_f32sums failed: {rc}")
         return flow
 
+    def calc_tracked(self, prev, nxt, p=None):
+        """calc() + the (H, W, 7) record of the finest layer's last sweep + flips (H, W) uint8: in how many of the finest layer's last
+        four updates a pixel's displaced position changed sides of the image border test (the iteration's one discontinuity)."""
+        p = p or default_params()
+        prev = np.ascontiguousarray(prev, np.uint8); nxt = np.ascontiguousarray(nxt, np.uint8)
+        H, W = prev.shape
+        flow = np.empty((H, W, 2), np.float32)
+        sys = np.full((H, W, 7), np.nan)
+        flips = np.zeros((H, W), np.uint8)
+        rc = self.lib.fbo_calc_track(_p(prev, C.c_uint8), _p(nxt, C.c_uint8), W, H, C.byref(p), _p(flow, C.c_float), _p(sys, C.c_double),
+                                     _p(flips, C.c_uint8))
+        if rc != 0:
+            raise ValueError(f"fbo_calc_track failed: {rc}")
+        return flow, sys, flips
+
+    def twins(self, prev, nxt, p=None):
+        """Two float32-sums re-runs of the restatement whose distance from calc() marks where its own result is not reproducible
+        (oracle/tolerances.py): calc_f32sums on the frames as they are, and on the horizontally MIRRORED frames (result mirrored
+        back, u negated) -- the same algorithm, mathematically the same flow, but every sliding sum runs the other way, so the
+        rounding differences are a second, independent sample.  NOT OpenCV, never an expected value."""
+        a = self.calc_f32sums(prev, nxt, p)
+        prev_m, nxt_m = np.ascontiguousarray(np.asarray(prev)[:, ::-1]), np.ascontiguousarray(np.asarray(nxt)[:, ::-1])
+        b = self.calc_f32sums(prev_m, nxt_m, p)[:, ::-1].copy()
+        b[..., 0] = -b[..., 0]
+        return [a, b]
+
     def pyramid(self, prev, nxt, p=None, on_sweep=None):
         """calc() driven layer by layer from Python with the stage functions above (bit-identical to calc(): tested).
         on_sweep(k, it, flow, M_before, sys, R0, R1) is called after every sweep (tools/worst_pixel.py)."""

@@ -607,6 +607,13 @@ def test_posted_step_errors_surface_at_wait_and_drain(mav):
             ctx.wait_step(999)
         with pytest.raises(ValueError):
             _lib.check(ctx.lib.mav_frame_step_dev(ctx.h, C.byref(bad)))
+    # a context destroyed with steps still queued: the worker finishes the one in hand, drops the rest, and the process goes on
+    ctx = _lib.Context(W, H, 1)
+    for _ in range(200):
+        ctx.post_step(ok)
+    ctx.close()
+    with _lib.Context(W, H, 1) as again:
+        again.wait_step(again.post_step(ok))
 
 
 def test_upload_gather_reads_page_locked_sources_before_it_returns(mav):

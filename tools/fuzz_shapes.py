@@ -48,11 +48,11 @@ def fuzz_cases(n_cases, seed):
 def main():
     from mavflow import _lib
     from oracle import fb_oracle, foe_oracle
-    from oracle.tolerances import check_flow, unstable_mask
+    from oracle.tolerances import check_flow, unstable_mask, flow_gate, epe
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     orc = fb_oracle.load()
-    worst, n_ill = 0.0, 0
+    worst, n_ill, n_excused = 0.0, 0, 0
     for cs in fuzz_cases(n_cases, seed):
         case, W, H, B, fb, po, prev, nxt, smp = (cs[k] for k in ("case", "W", "H", "B", "fb", "po", "prev", "nxt", "smp"))
         t0 = time.time()
@@ -68,17 +68,21 @@ def main():
             assert np.array_equal(c.farneback_sequence(run), two), (case, W, H, "sequence")
         for b in range(B):
             ref = orc.calc(prev[b], nxt[b], po)
-            twin = orc.calc_f32sums(prev[b], nxt[b], po)             # the oracle's own sensitivity: which pixels are unstable
-            e = check_flow(out["flow"][b], ref, (case, W, H), twin, fb.winsize // 2)
+            e = epe(out["flow"][b], ref)
+            if flow_gate(e) is not None:                             # outside the strict gate: is it where the oracle itself is unstable?
+                ref, _, flips = orc.calc_tracked(prev[b], nxt[b], po)
+                twins = orc.twins(prev[b], nxt[b], po)
+                e = check_flow(out["flow"][b], ref, (case, W, H, b), twins, fb.winsize // 2, flips)
+                n_excused += 1
+                n_ill += int(unstable_mask(ref, twins, fb.winsize // 2, flips).sum())
             worst = max(worst, float(e.max()))
-            n_ill += int(unstable_mask(ref, twin, fb.winsize // 2).sum())
             ch = foe_oracle.run_chain(out["flow"][b], smp[b])
             r = out["results"][b]
             assert tuple(r["foe"]) == tuple(ch["foe"]), (case, W, H, tuple(r["foe"]), ch["foe"])
             assert np.array_equal(out["mask_fixed"][b], ch["fixed"]) and np.array_equal(out["mask_dyn"][b], ch["total"]), (case, W, H)
             assert tuple(r["box"]) == tuple(ch["box"]), (case, W, H)
         print(f"case {case:3d}  {W:4d}x{H:<4d} B={B} layers={fb.levels} win={fb.winsize} it={fb.iterations} n={fb.poly_n}  ok ({time.time() - t0:.2f}s)", flush=True)
-    print(f"all {n_cases} cases passed; worst single-pixel EPE {worst:.3e} px; {n_ill} unstable pixels (oracle/tolerances.py)")
+    print(f"all {n_cases} cases passed; worst single-pixel EPE {worst:.3e} px; {n_excused} frames outside the strict gate, {n_ill} unstable pixels excused (oracle/tolerances.py)")
 
 
 if __name__ == "__main__":

@@ -8,8 +8,9 @@ the frame behind gpurun_out/fuzz80.log's 0.269 px), finds the worst pixel of the
      the cancellation in the determinant, the oracle's flow, the GPU's float32 flow after the same sweep (stage hooks, the GPU's own
      intermediates fed forward) and the EPE there, next to the layer's maximum EPE,
   3. the ONE-sweep error: the GPU's sweep applied to the ORACLE's M (what float32 sums cost per sweep, before feedback),
-  4. max EPE against three candidate explanations: conditioning of the 2x2 system, how far the oracle's iteration still moves,
-     and the oracle's own sensitivity to float32 rounding of its sums (the one oracle/tolerances.py gates on).
+  4. max EPE against candidate explanations: conditioning of the 2x2 system, how far the oracle's iteration still moves, the
+     oracle's own sensitivity to float32 rounding of its sums (two twins) and flips of the image-border test -- the last two are
+     what oracle/tolerances.py calls unstable.
 
 usage: python tools/worst_pixel.py [seed] [case]
 """
@@ -121,13 +122,19 @@ for lo, hi in zip(edges[:-1], edges[1:]):
     if m.any():
         print(f"   [{lo:8g}, {hi:8g})                          {int(m.sum()):10d}   {E[m].max():10.3e}   {E[m].mean():10.3e}")
 print(f"   worst pixel: the oracle's flow moved {st_all[b, y, x]:.3f} px in the last sweep (window maximum)")
-S_all = np.stack([sensitivity(refs[i][0], orc.calc_f32sums(prev[i], nxt[i], po), fb.winsize // 2) for i in range(B)])
-edges = [0, 1e-5, 1e-4, 1e-3, 1e-2, 0.05, FLOW_UNSTABLE_S, 0.5, 1, np.inf]
-print("   S = |calc - calc_f32sums|, window maximum [px)     pixels      max EPE     mean EPE")
+from oracle.tolerances import _window_max, unstable_mask
+tw_all = [orc.twins(prev[i], nxt[i], po) for i in range(B)]
+S_all = np.stack([sensitivity(refs[i][0], tw_all[i], fb.winsize // 2) for i in range(B)])
+flips_b = orc.calc_tracked(prev[b], nxt[b], po)[2]
+fl_b = _window_max((flips_b > 0).astype(np.float64), fb.winsize // 2) > 0
+edges = [0, 1e-5, 1e-4, 1e-3, FLOW_UNSTABLE_S, 0.05, 0.15, 0.5, 1, np.inf]
+print("   S = max over the oracle's two float32-sums twins of |calc - twin|, window maximum [px)     pixels      max EPE     mean EPE")
 for lo, hi in zip(edges[:-1], edges[1:]):
     m = (S_all >= lo) & (S_all < hi)
     if m.any():
         print(f"   [{lo:8g}, {hi:8g})                          {int(m.sum()):10d}   {E[m].max():10.3e}   {E[m].mean():10.3e}")
-print(f"   worst pixel: the oracle's own float32-sums twin is {S_all[b, y, x]:.3f} px away (window maximum); unstable pixels of the pair "
-      f"(S >= {FLOW_UNSTABLE_S}): {int((S_all[b] >= FLOW_UNSTABLE_S).sum())} = {(S_all[b] >= FLOW_UNSTABLE_S).mean():.2e} of the frame; "
-      f"max EPE outside them: {E[b][S_all[b] < FLOW_UNSTABLE_S].max():.3e} px")
+un_b = unstable_mask(refs[b][0], tw_all[b], fb.winsize // 2, flips_b)
+print(f"   worst pixel: S = {S_all[b, y, x]:.3f} px; a pixel of its window changed sides of the image-border test in the last four updates: {bool(fl_b[y, x])} "
+      f"({int((flips_b > 0).sum())} such pixels in the frame)")
+print(f"   unstable pixels of the pair (S >= {FLOW_UNSTABLE_S} or flipped): {int(un_b.sum())} = {un_b.mean():.2e} of the frame; over the stable rest: "
+      f"mean {E[b][~un_b].mean():.3e}  p99.9 {np.percentile(E[b][~un_b], 99.9):.3e}  max {E[b][~un_b].max():.3e} px")
