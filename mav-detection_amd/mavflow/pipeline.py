@@ -664,12 +664,14 @@ class DetectPipeline:
         return si
 
     def _wait_slot(self, s) -> None:
-        if s.ticket:
-            self.ctx.wait_step(s.ticket, s.marker)
-        else:
-            check(self.ctx.lib.mav_marker_wait(None, s.marker))
-        s.busy = False
-        s.keep = None
+        try:
+            if s.ticket:
+                self.ctx.wait_step(s.ticket, s.marker)
+            else:
+                check(self.ctx.lib.mav_marker_wait(None, s.marker))
+        finally:                                          # a step that failed has nothing more to wait for: the slot is free either way
+            s.busy = False
+            s.keep = None
 
     def collect(self, ticket: int) -> dict:
         """Wait for that batch (and only that batch) and return its records (n,) RESULT_DTYPE, the (n, 4) int64 counts of both masks
