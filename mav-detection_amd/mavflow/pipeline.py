@@ -9,12 +9,13 @@ is a 32-byte record plus eight integers.  This module provides
     DeviceArray     an array-like handle of a result that stays on the device until somebody LOOKS at it (np.asarray, indexing,
                     arithmetic); Processor.flow_uv / estimate_fixed / total_mask are such handles in the fast loops, so code that
                     reads them still works and code that does not pays nothing.
-    FlowStage       Dataset.get_flow_uv's Farneback seam (src/datasets/dataset.py:205-212) without the round trip: two frames in
-                    (mav_upload_gather), flow left on the device in one of two alternating buffers, DeviceArray out.
-    DetectPipeline  mav_process_batch_dev / mav_detect_dev + mav_tpr_fpr_counts_dev with double-buffered slots: submit(batch k + 1)
-                    while batch k computes, collect(batch k) waits for batch k's marker only.  Frames are handed over as the reference
-                    has them -- one numpy array per frame -- and gathered into the slot's device buffers by the library's staging
-                    threads (mav_upload_gather); records and counts come back through page-locked blocks.
+    FlowStage       Dataset.get_flow_uv's Farneback seam (src/datasets/dataset.py:205-212) without the round trip: frames in, flow left
+                    on the device in one of two alternating buffers, DeviceArray out -- DEFERRED: nothing is enqueued until the handle
+                    reaches a DetectPipeline (then upload + Farneback + detection are one step) or somebody reads it.
+    DetectPipeline  one mav_frame_step per submit (uploads of the caller's per-frame arrays, Farneback, detection, TPR / FPR counts, result
+                    download, marker), posted to the context's worker thread; double-buffered slots: submit(batch k + 1) while batch k
+                    computes, collect(batch k) waits for batch k only; records and counts come back through page-locked blocks.
+    Laned...        the same over several contexts taken in turn, one stream each, in a priority class of their own.
 
 Nothing here computes: every number is produced by the kernels behind include/mavflow.h.
 """
