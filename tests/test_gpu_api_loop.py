@@ -662,28 +662,31 @@ def test_retired_handles_dropped_at_once_do_not_leak_their_blocks_to_another_lan
     lanes = [_lib.Context(W, H, 1) for _ in range(2)]
     for c in lanes:
         c.set_option("inline_uploads", 1)
-    pipes = [DetectPipeline(c, 1, slots=2) for c in lanes]
+    pipes = [DetectPipeline(c, 1, slots=3) for c in lanes]
     pool = _lib._pinned
     seen_pending = 0
     for rnd in range(12):
         a, b = rnd & 1, (rnd & 1) ^ 1
         oa = pipes[a].collect(pipes[a].submit(smp[a], prev=[prev[a]], nxt=[nxt[a]]))
-        # lane a: a long batch behind which the retiring copies queue up, then retire lane a's handles and drop them immediately
-        t = pipes[a].submit(smp[a], prev=[prev[a]], nxt=[nxt[a]])
+        # lane a: two more batches behind which the retiring copies queue up (~0.4 ms of kernels), then retire lane a's handles and
+        # drop them immediately
+        ts = [pipes[a].submit(smp[a], prev=[prev[a]], nxt=[nxt[a]]) for _ in range(2)]
         held = [oa["mask_fixed"][0], oa["mask_dyn"][0]]
-        refs = pipes[a].slots[0].handles + pipes[a].slots[1].handles
-        _retire_all([r for r in refs if r() is not None])
+        refs = [r for sl in pipes[a].slots for r in sl.handles if r() is not None]
+        _retire_all(refs)
         assert all(h._pending is not None for h in held)
         del held, oa
         seen_pending += len(pool.pending)
         # lane b: same-size handles materialised right now -- they take blocks from the pool
         ob = pipes[b].collect(pipes[b].submit(smp[b], prev=[prev[b]], nxt=[nxt[b]]))
-        for key, buf in (("mask_fixed", pipes[b].slots[(pipes[b]._turn - 1) % 2].mf), ("mask_dyn", pipes[b].slots[(pipes[b]._turn - 1) % 2].md)):
+        sb = pipes[b].slots[(pipes[b]._turn - 1) % 3]
+        for key, buf in (("mask_fixed", sb.mf), ("mask_dyn", sb.md)):
             got = np.asarray(ob[key][0]).copy()
             lanes[a].sync()                                                              # lane a's late copies land now (into blocks nobody else may hold)
             sync = buf.download(np.uint8, (H, W)).view(np.bool_)
             assert np.array_equal(got, sync) and np.array_equal(np.asarray(ob[key][0]), sync), (rnd, key)
-        pipes[a].collect(t)
+        for t in ts:
+            pipes[a].collect(t)
     assert seen_pending > 0, "the scenario never had a block waiting for its copy: the test did not exercise the guard"
     for p in pipes:
         p.close()
