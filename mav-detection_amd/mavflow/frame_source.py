@@ -3,13 +3,15 @@
 cv2 is not part of this build; this module is that capture for PNG sequences:
 
     decode_png(bytes) -> u8 array        chunk parsing + zlib inflate (Python stdlib), un-filtering in libmavflow (mav_png_unfilter:
-                                         two of PNG's five filters are per-pixel recurrences).  Non-interlaced, bit depth 8 (gray,
-                                         gray + alpha, RGB, RGBA, palette) and depths 1 / 2 / 4 for gray and palette images.
+                                         two of PNG's five filters are per-pixel recurrences).  Every colour type (gray, gray + alpha,
+                                         RGB, RGBA, palette) at every legal bit depth (1 / 2 / 4 / 8 / 16), non-interlaced and Adam7
+                                         interlaced; 16-bit samples are narrowed to their high byte, which is what cv2.imread's
+                                         default flag does (libpng's png_set_strip_16).
     imread(path) -> BGR u8 (H, W, 3)     what cv2.imread(path) (IMREAD_COLOR) returns: gray replicated, alpha dropped, palette expanded.
     PngSequenceCapture(pattern)          cv2.VideoCapture(pattern)'s read() / get(3|4|7) / isOpened() / release() for an image sequence.
 
-16-bit and interlaced files raise NotImplementedError (cv2 narrows / de-interlaces them; nothing here can pin how).  The decoder is
-pinned by PIL-decoded fixtures generated in the build container (tools/gen_png_fixtures.py, tests/golden/png_frames.npz).
+The decoder is pinned by PIL-decoded fixtures generated in the build container (tools/gen_png_fixtures.py,
+tests/golden/png_frames.npz), 16-bit and interlaced files included (round 6).
 """
 from __future__ import annotations
 
@@ -59,28 +61,50 @@ def decode_png(data: bytes) -> Tuple[np.ndarray, int]:
     W, H, depth, ctype, comp, filt, interlace = ihdr
     if ctype not in _CHANNELS or comp != 0 or filt != 0:
         raise ValueError(f"unsupported PNG header (colour type {ctype}, compression {comp}, filter method {filt})")
-    if interlace != 0:
-        raise NotImplementedError("interlaced (Adam7) PNG files are not supported")
-    if depth == 16:
-        raise NotImplementedError("16-bit PNG files are not supported")
-    if depth not in (1, 2, 4, 8) or (depth < 8 and ctype not in (0, 3)):
+    if interlace not in (0, 1):
+        raise ValueError(f"unknown PNG interlace method {interlace}")
+    if depth not in (1, 2, 4, 8, 16) or (depth < 8 and ctype not in (0, 3)) or (depth == 16 and ctype == 3):
         raise ValueError(f"invalid PNG bit depth {depth} for colour type {ctype}")
     ch = _CHANNELS[ctype]
-    stride = (W * ch * depth + 7) // 8
-    raw = zlib.decompress(b"".join(idat))
-    if len(raw) != H * (stride + 1):
-        raise ValueError(f"PNG image data holds {len(raw)} bytes, {H * (stride + 1)} expected")
-    out = np.empty((H, stride), np.uint8)
-    src = np.frombuffer(raw, np.uint8)
-    _lib.check(_lib.load().mav_png_unfilter(src.ctypes.data, H, stride, max(1, ch * depth // 8), out.ctypes.data))
-    if depth < 8:                                    # samples packed most significant bit first; gray levels scale to 0 .. 255
-        bits = np.unpackbits(out, axis=1)[:, :W * depth].reshape(H, W, depth)
-        vals = np.zeros((H, W), np.uint8)
-        for b in range(depth):
-            vals = (vals << 1) | bits[..., b]
-        out = vals if ctype == 3 else (vals * (255 // ((1 << depth) - 1))).astype(np.uint8)
-    else:
-        out = out.reshape(H, W) if ch == 1 else out.reshape(H, W, ch)
+    raw = np.frombuffer(zlib.decompress(b"".join(idat)), np.uint8)
+    lib = _lib.load()
+
+    def samples(off, pw, ph):
+        """one (sub-)image of pw x ph pixels starting at byte `off` of the inflated stream -> ((ph, pw * ch) u8 sample values, next offset)"""
+        stride = (pw * ch * depth + 7) // 8
+        n = ph * (stride + 1)
+        if off + n > len(raw):
+            raise ValueError(f"PNG image data holds {len(raw)} bytes, more expected")
+        rows = np.empty((ph, stride), np.uint8)
+        _lib.check(lib.mav_png_unfilter(raw[off:off + n].ctypes.data, ph, stride, max(1, ch * depth // 8), rows.ctypes.data))
+        if depth == 8:
+            v = rows
+        elif depth == 16:                            # big-endian 16-bit samples -> their high byte (png_set_strip_16)
+            v = np.ascontiguousarray(rows.reshape(ph, pw * ch, 2)[..., 0])
+        else:                                        # samples packed most significant bit first
+            bits = np.unpackbits(rows, axis=1)[:, :pw * depth].reshape(ph, pw, depth)
+            v = np.zeros((ph, pw), np.uint8)
+            for b in range(depth):
+                v = (v << 1) | bits[..., b]
+        return v, off + n
+
+    if interlace == 0:
+        out, end = samples(0, W, H)
+    else:                                            # Adam7: seven reduced images, each filtered on its own, scattered onto the 8 x 8 lattice
+        out = np.empty((H, W * ch), np.uint8)
+        grid = out.reshape(H, W, ch)
+        end = 0
+        for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+            pw, ph = (W - x0 + dx - 1) // dx, (H - y0 + dy - 1) // dy
+            if pw <= 0 or ph <= 0:
+                continue                             # an empty pass has no bytes at all, not even filter bytes
+            v, end = samples(end, pw, ph)
+            grid[y0::dy, x0::dx] = v.reshape(ph, pw, ch)
+    if end != len(raw):
+        raise ValueError(f"PNG image data holds {len(raw)} bytes, {end} expected")
+    if depth < 8 and ctype == 0:                     # gray levels scale to 0 .. 255
+        out = (out * (255 // ((1 << depth) - 1))).astype(np.uint8)
+    out = out.reshape(H, W) if ch == 1 else out.reshape(H, W, ch)
     if ctype == 3:
         if plte is None:
             raise ValueError("palette PNG without PLTE chunk")

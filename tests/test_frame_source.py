@@ -2,7 +2,8 @@
 
 The PNG decoder (mavflow/frame_source.py; un-filtering in libmavflow's host function mav_png_unfilter, which needs no GPU) against
 fixtures PIL decoded in the build container (tools/gen_png_fixtures.py -> tests/golden/png_frames.npz): every colour type, bit
-depths 1 / 2 / 4 / 8, all five filters forced on every row position, PIL's own adaptive encoder, palette + tRNS, split IDAT.
+depths 1 / 2 / 4 / 8 / 16, all five filters forced on every row position, PIL's own adaptive encoder, palette + tRNS, split IDAT,
+Adam7-interlaced files of every colour type down to 1 x 1 pixels (empty passes).
 The JSON writer (Processor._store = src/processor.py:83-84) against the text the reference's own utils.get_json produced."""
 import json
 import logging
@@ -29,7 +30,7 @@ def _names(z):
 
 def test_every_fixture_decodes_to_what_pil_saw(png, tmp_path):
     names = _names(png)
-    assert len(names) >= 16
+    assert len(names) >= 36 and sum(n.startswith("adam7_") for n in names) >= 16 and sum("16" in n for n in names) >= 6
     for name in names:
         path = tmp_path / f"{name}.png"
         path.write_bytes(png["png_" + name].tobytes())
@@ -71,12 +72,20 @@ def test_malformed_and_unsupported_files(png, tmp_path):
         fs.decode_png(bytes(bad_crc))
     with pytest.raises(ValueError):
         fs.decode_png(good[:len(good) // 2])
+    # a header that lies about the layout of the data (interlace flag / bit depth flipped, data untouched): a pass runs into a byte
+    # that is no filter type, or the byte count does not add up
     interlaced = _rechunk(good, lambda k, b: b[:12] + b"\x01" if k == b"IHDR" else b)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):
         fs.decode_png(interlaced)
     deep = _rechunk(good, lambda k, b: b[:8] + b"\x10" + b[9:] if k == b"IHDR" else b)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError, match="bytes"):
         fs.decode_png(deep)
+    for hdr in (b"\x02", b"\x07"):                           # interlace method 2 does not exist; neither does bit depth 7
+        with pytest.raises(ValueError):
+            fs.decode_png(_rechunk(good, lambda k, b, hdr=hdr: (b[:12] + hdr if hdr == b"\x02" else b[:8] + hdr + b[9:]) if k == b"IHDR" else b))
+    pal16 = _rechunk(png["png_pal8_trns_forced"].tobytes(), lambda k, b: b[:8] + b"\x10" + b[9:] if k == b"IHDR" else b)
+    with pytest.raises(ValueError, match="bit depth"):
+        fs.decode_png(pal16)                                   # palette images have no 16-bit form
     # a filter-type byte outside 0 - 4 is refused by the library, and imread() maps every failure to cv2.imread's None
     def bad_filter(k, b):
         if k != b"IDAT":

@@ -6,7 +6,10 @@ there; it is not needed to run the tests):
 Per case: `png_<name>` = the file's bytes (uint8), `bgr_<name>` = cv2.imread's view of it derived from PIL's decode (RGB -> BGR, gray
 replicated, alpha dropped).  Files come from two encoders: PIL's own (adaptive filter choice) and the minimal encoder below, which
 forces filter type (row + k) % 5 on every row so that all five filters -- and their first-row / first-pixel edge cases -- occur in
-every colour type and bit depth."""
+every colour type and bit depth.  Round 6: 16-bit samples (cv2.imread's default flag narrows them to the high byte, libpng's
+png_set_strip_16 -- which is also what PIL's "RGB" view of a 16-bit RGB file holds; for 16-bit GRAY files PIL keeps all sixteen bits,
+so the expectation is its array >> 8) and Adam7-interlaced files (PIL reads them; the encoder below writes the seven passes, every pass
+filtered on its own, sizes down to 1 x 1 so that empty passes occur).  Nothing here needs cv2."""
 import io
 import os
 import struct
@@ -27,6 +30,51 @@ def paeth(a, b, c):
     p = a + b - c
     pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
     return a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+
+
+def filter_rows(rows_bytes, bpp, first_filter):
+    """(H, stride) u8 of packed samples -> the filtered byte stream.  Filter type of row y = (y + first_filter) % 5."""
+    H, stride = rows_bytes.shape
+    raw = bytearray()
+    prev = np.zeros(stride, np.int64)
+    for y in range(H):
+        cur = rows_bytes[y].astype(np.int64)
+        ft = (y + first_filter) % 5
+        out = np.zeros(stride, np.int64)
+        for i in range(stride):
+            a = cur[i - bpp] if i >= bpp else 0
+            b = prev[i]
+            c = prev[i - bpp] if i >= bpp else 0
+            pred = (0, a, b, (a + b) >> 1, paeth(a, b, c))[ft]
+            out[i] = (cur[i] - pred) & 255
+        raw.append(ft)
+        raw += bytes(out.astype(np.uint8))
+        prev = cur
+    return bytes(raw)
+
+
+ADAM7 = ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2))
+
+
+def encode_adam7(samples, depth, ctype, first_filter=0, extra=b""):
+    """samples: (H, W, ch) integer sample values (< 2^depth) -> an Adam7-interlaced PNG file."""
+    H, W, ch = samples.shape
+    bpp = max(1, ch * depth // 8)
+    raw = b""
+    for k, (x0, y0, dx, dy) in enumerate(ADAM7):
+        sub = samples[y0::dy, x0::dx]
+        if sub.shape[0] == 0 or sub.shape[1] == 0:
+            continue
+        ph, pw = sub.shape[:2]
+        if depth == 16:
+            rows = sub.astype(">u2").reshape(ph, -1).view(np.uint8)
+        elif depth == 8:
+            rows = sub.astype(np.uint8).reshape(ph, -1)
+        else:
+            rows = pack_bits(sub[..., 0].astype(np.uint8), depth)
+        raw += filter_rows(np.ascontiguousarray(rows), bpp, first_filter + k)
+    ihdr = struct.pack(">IIBBBBB", W, H, depth, ctype, 0, 0, 1)
+    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", ihdr) + extra + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b"")
 
 
 def encode(rows_bytes, W, H, depth, ctype, bpp, first_filter=0, extra=b"", idat_split=1):
@@ -63,6 +111,9 @@ def pack_bits(vals, depth):
 def as_bgr(png_bytes):
     im = Image.open(io.BytesIO(png_bytes))
     im.load()
+    if im.mode.startswith("I;16") or im.mode == "I":       # 16-bit gray: PIL keeps sixteen bits (and its own convert() CLAMPS them);
+        hi = (np.asarray(im).astype(np.uint32) >> 8).astype(np.uint8)      # cv2.imread's default flag strips to the high byte
+        return np.repeat(hi[..., None], 3, axis=2)
     rgb = np.asarray(im.convert("RGB"))
     return np.ascontiguousarray(rgb[..., ::-1])
 
@@ -103,6 +154,27 @@ def main():
     buf = io.BytesIO()
     Image.fromarray(smooth(30, 40, 3), "RGB").quantize(32).save(buf, format="PNG")
     cases["pal_pil"] = buf.getvalue()
+    # 16-bit samples, non-interlaced: gray, RGB, RGBA, gray + alpha
+    g16 = rng.integers(0, 65536, (13, 17)).astype(">u2")
+    cases["gray16_forced"] = encode(g16.reshape(13, -1).view(np.uint8), 17, 13, 16, 0, 2, first_filter=2)
+    rgb16 = rng.integers(0, 65536, (11, 14, 3)).astype(">u2")
+    cases["rgb16_forced"] = encode(rgb16.reshape(11, -1).view(np.uint8), 14, 11, 16, 2, 6, first_filter=4)
+    rgba16 = rng.integers(0, 65536, (9, 10, 4)).astype(">u2")
+    cases["rgba16_forced"] = encode(rgba16.reshape(9, -1).view(np.uint8), 10, 9, 16, 6, 8, first_filter=1)
+    la16 = rng.integers(0, 65536, (7, 9, 2)).astype(">u2")
+    cases["graya16_forced"] = encode(la16.reshape(7, -1).view(np.uint8), 9, 7, 16, 4, 4, first_filter=3)
+    # Adam7: every colour type, depths 1 .. 16, sizes with empty passes (1 x 1, 2 x 2, 3 x 5), one larger than two lattice cells
+    cases["adam7_gray8"] = encode_adam7(smooth(21, 19, 1), 8, 0, first_filter=1)
+    cases["adam7_rgb8"] = encode_adam7(smooth(18, 23, 3), 8, 2, first_filter=3)
+    cases["adam7_rgba8"] = encode_adam7(smooth(9, 12, 4), 8, 6, first_filter=0)
+    cases["adam7_graya8"] = encode_adam7(smooth(10, 7, 2), 8, 4, first_filter=2)
+    for depth in (1, 2, 4):
+        cases[f"adam7_gray{depth}"] = encode_adam7(rng.integers(0, 1 << depth, (11, 13, 1)), depth, 0, first_filter=depth)
+    cases["adam7_pal4"] = encode_adam7(rng.integers(0, 16, (12, 9, 1)), 4, 3, first_filter=4, extra=chunk(b"PLTE", pal.tobytes()))
+    cases["adam7_rgb16"] = encode_adam7(rng.integers(0, 65536, (8, 9, 3)), 16, 2, first_filter=2)
+    cases["adam7_gray16"] = encode_adam7(rng.integers(0, 65536, (9, 8, 1)), 16, 0, first_filter=0)
+    for (h, w) in ((1, 1), (2, 2), (3, 5), (5, 3), (1, 9), (9, 1)):
+        cases[f"adam7_rgb8_{w}x{h}"] = encode_adam7(smooth(h, w, 3), 8, 2, first_filter=h + w)
     out = {}
     for name, data in cases.items():
         out["png_" + name] = np.frombuffer(data, np.uint8)
