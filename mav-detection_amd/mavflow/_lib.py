@@ -285,7 +285,7 @@ class _PinnedPool:
             self.idle_bytes -= nbytes
         else:
             p = C.c_void_p()
-            check(ctx.lib.mav_host_alloc(ctx.h, nbytes, C.byref(p)))
+            check(ctx.lib.mav_host_alloc(ctx._h, nbytes, C.byref(p)))
             ptr = p.value
         # the finalizer hangs on the ctypes object that OWNS the memory in numpy's eyes: every array or view derived from it
         # (numpy collapses view chains onto the owner) keeps it alive, so the block returns only when the last of them is gone
@@ -329,7 +329,7 @@ class DeviceBuffer:
     def __init__(self, ctx: "Context", nbytes: int):
         self.ctx, self.nbytes = ctx, int(nbytes)
         p = C.c_void_p()
-        check(ctx.lib.mav_dev_alloc(ctx.h, self.nbytes, C.byref(p)))
+        check(ctx.lib.mav_dev_alloc(ctx._h, self.nbytes, C.byref(p)))      # (an allocation touches no stream: no need to drain the worker)
         self.ptr = p.value
 
     def upload(self, a: np.ndarray):

@@ -1,5 +1,6 @@
-"""Where a batch of Processor.run_detection_batched goes on the host: wall time inside submit() (gathering the frames into the slot's
-device buffers + enqueueing), inside collect() (waiting for the batch's marker) and in the FrameResult tail, per batch.
+"""Where a batch of Processor.run_detection_batched goes on the host: wall time inside submit() (since round 6: assembling ONE
+mav_frame_step and posting it to the context's worker thread, which gathers the frames and enqueues the batch), inside collect()
+(waiting for the batch's step and marker) and in the FrameResult tail, per batch.
 usage: python tools/api_loop_breakdown.py [batch] [batches] [upload_threads] [distinct pairs] [video]"""
 import sys, time, logging
 sys.path.insert(0, "."); sys.path.insert(0, "mav-detection_amd")
@@ -37,7 +38,7 @@ pipeline.DetectPipeline.submit, pipeline.DetectPipeline.collect = submit, collec
 # ... and the library calls inside submit()
 from mavflow import _lib
 lib = _lib.load()
-for name in ("mav_upload_gather", "mav_process_batch_dev", "mav_tpr_fpr_counts_dev", "mav_upload_async_unordered", "mav_upload_fence", "mav_marker_wait"):
+for name in ("mav_frame_step_post", "mav_frame_step_wait", "mav_worker_drain", "mav_upload_gather", "mav_marker_wait"):
     acc[name] = []
 
     def wrap(fn, name=name):
@@ -45,9 +46,10 @@ for name in ("mav_upload_gather", "mav_process_batch_dev", "mav_tpr_fpr_counts_d
             t0 = time.perf_counter(); r = fn(*a); acc[name].append(time.perf_counter() - t0); return r
         return w
     setattr(lib, name, wrap(getattr(lib, name)))
-ds.N = batch + 1
+ds.N = 3 * batch + 1                                            # (three slots: all of them get their buffers in the warm run)
 p.run_detection_batched(batch=batch)
 p.frame_index = 0; p.detection_results = {}
+p.flow_uv = p.estimate_fixed = p.total_mask = None          # a fresh run holds no handles of an earlier one
 for k in acc:
     acc[k].clear()
 ds.N = N
@@ -58,7 +60,7 @@ ms = lambda v: " ".join(f"{1e3 * x:6.2f}" for x in v)
 print(f"{W}x{H} batch {batch} x {batches}, upload_threads {threads or 'default'}, {distinct} distinct pairs{' of one video' if video else ''}: {(N - 1) / dt:.1f} pairs/s, {1e3 * dt / batches:.2f} ms per batch")
 print(f"  submit  per batch (ms): {ms(acc['submit'])}")
 print(f"  collect per batch (ms): {ms(acc['collect'])}")
-for name in ("mav_upload_gather", "mav_process_batch_dev", "mav_tpr_fpr_counts_dev", "mav_upload_async_unordered", "mav_upload_fence", "mav_marker_wait"):
+for name in ("mav_frame_step_post", "mav_frame_step_wait", "mav_worker_drain", "mav_upload_gather", "mav_marker_wait"):
     v = acc[name]
     print(f"  {name:28s} {len(v):4d} calls, {1e3 * sum(v) / batches:7.2f} ms per batch; per call (ms): {ms(v[:12])}")
 other = 1e3 * dt - 1e3 * sum(acc['submit']) - 1e3 * sum(acc['collect'])
