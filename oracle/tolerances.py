@@ -47,9 +47,20 @@ unstable pixel (up to 1.49 px).  Hence THE TWO-CLASS GATE, for a caller that han
 pinned regression cases, nobody else:
 
     a frame inside the strict gate passes as it is;
-    a frame outside it passes if its unstable pixels are at most 5 % of the frame (measured in the five frames: 2.3 - 3.6 %) and
-    none is further off than 4 px (a sanity bound: there is no accuracy claim on them), and over ALL OTHER pixels
-    mean <= 1e-4 px, p99.9 <= 1e-2 px and max <= 0.05 px  (measured: <= 3.2e-5 / 5.2e-3 / 1.8e-2).
+    a frame outside it passes if
+      (a) over the pixels that are not unstable  mean <= 1e-4 px, p99.9 <= 1e-2 px and max <= 0.05 px  -- so every pixel further off
+          than 0.05 px is an unstable one  (measured over the nine frames below: <= 3.2e-5 / 5.2e-3 / 1.8e-2),
+      (b) the pixels that USE the exception -- further off than 0.05 px -- are at most 0.5 % of the frame (measured 0.02 - 0.17 %:
+          13 - 388 pixels beyond 0.15 px) and none is further off than 4 px (a sanity bound: no accuracy claim there),
+      (c) the unstable class is at most 10 % of the frame, so that (a) speaks for at least nine tenths of it (measured 2.3 - 6.0 %).
+
+OUT-OF-SAMPLE CHECK (profiles/r06/flow_gate_survey_oos.txt, strict_gate_failures.txt).  The criteria above were written from seeds
+0 - 4 and 123; six further seeds (5 - 10, 1 071 frames) were run afterwards.  Four more frames fail the strict gate (0.18 - 0.35 px), all
+four with every off pixel on an unstable one and stable pixels within 9.2e-3 px -- (a) and the sanity bound held unchanged.  What did NOT
+hold was the first form of (c), "unstable pixels <= 5 % of the frame" (3.6 % at most in the first six seeds): seed 5 / case 43 has 5.4 %
+and 6.0 % in two of its pairs.  The share of unstable pixels is a property of the restatement alone (frames well inside the strict gate
+have up to 59 %), not of the GPU's distance from it, so the bound that matters was moved to where the GPU is measured -- (b), new --
+and (c) widened to 10 %.  tests/test_gpu_flow.py pins that frame too.
 
 Candidate criteria the survey rejected: the last sweep's determinant or cancellation (the worst pixels have ordinary ones); how far
 the oracle's flow moved in its last sweep (5 - 15 % of all pixels move more than 0.02 px there and are perfectly reproducible);
@@ -66,7 +77,8 @@ FLOW_EPE_MAX = 0.15            # px, any pixel, strict gate (worst measured on a
 FLOW_EPE_MAX_STABLE = 0.05     # px, any stable pixel of a frame that needed its unstable pixels excused (worst measured: 0.018; 0.034 over all frames)
 FLOW_UNSTABLE_S = 0.01         # px: one of the oracle's own float32-sums twins moves at least this far (window maximum) -> unstable pixel
 FLOW_EPE_SANITY_UNSTABLE = 4.0 # px, any unstable pixel: no accuracy claim there, only that nothing is wild
-FLOW_UNSTABLE_FRAC = 5e-2      # unstable pixels per frame at most, in a frame that fails the strict gate (measured: 2.3 - 3.6 %)
+FLOW_UNSTABLE_FRAC = 0.10      # unstable pixels per frame at most, in a frame that fails the strict gate (measured: 2.3 - 6.0 %; 5 % until the out-of-sample seeds)
+FLOW_EXCUSED_FRAC = 5e-3       # pixels beyond FLOW_EPE_MAX_STABLE (all of them unstable) per frame at most (measured: 0.02 - 0.17 %)
 FLOW_GATE_TEXT = f"mean <= {FLOW_EPE_MEAN:g} px, p99.9 <= {FLOW_EPE_P999:g} px, max <= {FLOW_EPE_MAX:g} px"
 
 
@@ -140,7 +152,8 @@ def flow_gate(e, unstable=None):
     """None when the end-point-error field `e` (H, W) is inside the gate, else the name of the first gate it fails.
     `unstable`: boolean (H, W) from unstable_mask(), or None = no pixel is excused.  A frame inside the strict gate passes as it
     is; only a frame that fails it is looked at again with its unstable pixels set aside -- those may be at most FLOW_UNSTABLE_FRAC
-    of the frame and nothing wild, and every statistic of the strict gate must hold over the rest."""
+    of the frame and nothing wild, the pixels beyond FLOW_EPE_MAX_STABLE at most FLOW_EXCUSED_FRAC of it, and every statistic of the
+    strict gate (with that tighter maximum) must hold over the rest."""
     e = np.asarray(e)
     if not np.isfinite(e).all():
         return "non-finite EPE"
@@ -151,6 +164,8 @@ def flow_gate(e, unstable=None):
         return f"{failed}; too many unstable pixels to excuse"
     if e[unstable].max() > FLOW_EPE_SANITY_UNSTABLE:
         return "max EPE (unstable pixels)"
+    if (e > FLOW_EPE_MAX_STABLE).mean() > FLOW_EXCUSED_FRAC:
+        return f"{failed}; too many pixels beyond {FLOW_EPE_MAX_STABLE:g} px"
     return _strict(e[~unstable], " (stable pixels)", FLOW_EPE_MAX_STABLE) if (~unstable).any() else None
 
 
